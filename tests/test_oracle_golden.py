@@ -1,0 +1,202 @@
+"""Pin the CPU oracle (oracle/chain_ref.py) against fixtures produced by the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import scipy.signal
+
+from oracle import chain_ref as R
+
+RATE = 48000
+HOUR = 172_800_000
+KINDS = ('Sine', 'Square', 'Sawtooth', 'Triangle')
+
+
+def same(a, b):
+    """bit-for-bit, NaNs in the same places"""
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+# ------------------------------------------------------------------ oscillators (A6)
+@pytest.mark.parametrize('kind', KINDS)
+def test_osc_bit_exact(golden, kind):
+    g = golden('osc')
+    for pos in g['osc/positions']:
+        ref = g[f'osc/{kind}/p{int(pos)}']
+        got = R.osc(kind, int(pos), int(g['osc/frames']), RATE, g['osc/hertz'], g['osc/phase'])
+        assert same(got, ref), (kind, pos)
+    assert same(R.osc(kind, 256, 256, RATE, g['osc/hertz'], None), g[f'osc/{kind}/nophase/p256'])
+    assert same(R.osc(kind, 0, 64, RATE, g['osc/edge/hertz'], g['osc/edge/phase']), g[f'osc/edge/{kind}'])
+    assert same(R.osc(kind, 1000, 128, RATE, g['osc/neg/hertz'], g['osc/neg/phase']), g[f'osc/neg/{kind}'])
+
+
+def test_osc_int_hertz_and_ctrl(golden):
+    g = golden('osc')
+    assert same(R.osc('Sine', 0, 256, RATE, np.array([[220]])), g['osc/int_hertz/Sine'])
+    assert same(R.osc('Sine', 512, 1, RATE, g['osc/hertz'], g['osc/phase']), g['osc/ctrl/Sine/p512'])
+
+
+def test_square_is_zero_at_half(golden):
+    # sign(0.5 - mod(t,1)) is exactly 0 where mod == 0.5
+    assert (golden('osc')['osc/edge/Square'] == 0).any()
+
+
+# ------------------------------------------------------------------ filters (A7)
+@pytest.mark.parametrize('fname,btype', (('LowPass', 'lp'), ('HighPass', 'hp')))
+@pytest.mark.parametrize('oname', ('Sine', 'Sawtooth'))
+def test_single_filter_bit_exact(golden, fname, btype, oname):
+    g = golden('filter')
+
+    def src(p, n):
+        return R.osc(oname, p, n, RATE, g['filt/hertz'], g['filt/phase'])
+
+    for pos in g['filt/positions']:
+        ref = g[f'filt/{fname}/{oname}/p{int(pos)}']
+        got = R.filter_block(btype, src, int(pos), 256, RATE, g['filt/cutoff'])
+        assert same(got, ref), (fname, oname, pos)
+
+
+def test_filter_ragged_and_short_context(golden):
+    g = golden('filter')
+
+    def src(p, n):
+        return R.osc('Triangle', p, n, RATE, g['filt/hertz'], g['filt/phase'])
+
+    for pos, n in ((7, 33), (99, 101), (100, 64), (101, 1000)):
+        got = R.filter_block('lp', src, pos, n, RATE, g['filt/cutoff'])
+        assert same(got, g[f'filt/ragged/p{pos}_n{n}']), (pos, n)
+
+
+def test_closed_form_design_matches_scipy():
+    for btype in ('lp', 'hp'):
+        for hz in np.geomspace(1.0, 23999.0, 200):
+            wn = hz / 24000
+            ref = scipy.signal.butter(2, wn, btype, output='sos')
+            assert np.max(np.abs(R.butter2_sos(wn, btype) - ref)) < 4e-15
+    with pytest.raises(ValueError):
+        R.butter2_sos(0.0, 'lp')
+    with pytest.raises(ValueError):
+        R.butter2_sos(1.0, 'hp')
+
+
+def test_df2t_loop_is_sosfilt_bitwise():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(400)
+    for hz in (50, 200, 1000, 8000, 20000):
+        for btype in ('lp', 'hp'):
+            sos = scipy.signal.butter(2, hz / 24000, btype, output='sos')
+            assert np.array_equal(R.sosfilt_df2t(sos, x), scipy.signal.sosfilt(sos, x))
+
+
+def test_closed_form_filter_within_1e12(golden):
+    """what the HIP kernel computes (closed-form design + DF2T) vs the reference output"""
+    g = golden('filter')
+
+    def src(p, n):
+        return R.osc('Sine', p, n, RATE, g['filt/hertz'], g['filt/phase'])
+
+    for pos in (0, 50, HOUR):
+        got = R.filter_block('lp', src, pos, 256, RATE, g['filt/cutoff'], closed_form=True, loop=True)
+        assert np.max(np.abs(got - g[f'filt/LowPass/Sine/p{pos}'])) < 1e-12
+
+
+# ------------------------------------------------------------------ graph-level: cache + cascade (A3/A4/A9)
+def test_sequential_single_filter(golden):
+    g = golden('filter')
+    o = R.Osc('Sine', R.Fixed(g['filt/hertz']), R.Fixed(g['filt/phase']))
+    f = R.Filter('lp', o, R.Fixed(g['filt/seq/cutoff']))
+    assert same(R.render_stream(f, 0, 256, 4, 16), g['filt/seq/LowPass'])
+
+
+@pytest.mark.parametrize('N', (256, 1024))
+def test_cascade_sequential(golden, N):
+    g = golden('cascade')
+    o = R.Osc('Sawtooth', R.Fixed(g['casc/hertz']), R.Fixed(g['casc/phase']))
+    f1 = R.Filter('lp', o, R.Fixed(g['casc/cut1']))
+    f2 = R.Filter('lp', f1, R.Fixed(g['casc/cut2']))
+    assert same(R.render_stream(f2, 0, N, 4, 8), g[f'casc/seq_n{N}'])
+
+
+def test_cascade_fresh_graph(golden):
+    g = golden('cascade')
+    o = R.Osc('Sawtooth', R.Fixed(g['casc/hertz']), R.Fixed(g['casc/phase']))
+    f1 = R.Filter('lp', o, R.Fixed(g['casc/cut1']))
+    f2 = R.Filter('hp', f1, R.Fixed(g['casc/cut2']))
+    assert same(R.render(f2, 768, 256, 8), g['casc/fresh_p768'])
+
+
+def test_cascade_is_history_dependent(golden):
+    """A9: block 3 rendered on a fresh graph differs from the sequential render."""
+    g = golden('cascade')
+
+    def build():
+        o = R.Osc('Sawtooth', R.Fixed(g['casc/hertz']), R.Fixed(g['casc/phase']))
+        return R.Filter('lp', R.Filter('lp', o, R.Fixed(g['casc/cut1'])), R.Fixed(g['casc/cut2']))
+
+    fresh = R.render(build(), 768, 256, 8)
+    assert np.max(np.abs(fresh - g['casc/seq_n256'][768:1024])) > 1e-6
+
+
+# ------------------------------------------------------------------ effects (A8) and protocol corners
+def test_effects(golden):
+    g = golden('effects')
+    V, N, pos = 8, 128, 300
+    hz, ph = g['fxs/hertz'], g['fxs/phase']
+
+    def o(kind, s=1.0):
+        return R.Osc(kind, R.Fixed(hz * s), R.Fixed(ph))
+
+    assert same(R.render(R.Binary('Gain', o('Sine'), R.Fixed(g['fxs/gain'])), pos, N, V), g['fxs/Gain'])
+    assert same(R.render(R.Binary('Gain', o('Sine'), R.Fixed([[0.2]])), pos, N, V), g['fxs/Gain_scalar'])
+    assert same(R.render(R.Binary('Mix', o('Sine'), o('Sawtooth', 0.5), R.Fixed(g['fxs/gain'])), pos, N, V),
+                g['fxs/Mix'])
+    assert same(R.render(R.Binary('RingMod', o('Sine'), o('Triangle', 0.25)), pos, N, V), g['fxs/RingMod'])
+    e = g['fxs/amp_exp']
+    assert same(R.render(R.Binary('Amp', o('Sawtooth'), R.Fixed(np.round(e))), pos, N, V), g['fxs/Amp_int'])
+    frac = R.render(R.Binary('Amp', o('Sawtooth'), R.Fixed(e)), pos, N, V)
+    assert same(frac, g['fxs/Amp_frac']) and np.isnan(frac).any()
+    assert same(R.render(R.Merge(o('Sine'), o('Square', 0.5), V, V), pos, N, 2 * V), g['fxs/Merge'])
+
+
+def test_protocol_corners(golden):
+    g = golden('effects')
+    V, N, pos = 8, 128, 300
+    o = R.Osc('Sine', R.Fixed(g['fxs/hertz']), R.Fixed(g['fxs/phase']))
+    o.enabled = False
+    assert same(R.render(o, pos, N, V), g['fxs/disabled']) and g['fxs/disabled'].shape == (1, 1)
+    assert same(R.render(R.Binary('Gain', None, R.Fixed(g['fxs/gain'])), pos, N, V), g['fxs/unplugged_left'])
+    b = R.render(R.Osc('Sine', R.Fixed([[440.0]])), 0, N, 2)
+    assert same(b, g['fxs/broadcast_1to2']) and b.shape == (N, 1)
+
+
+def test_sigs_topologies(golden):
+    g = golden('sigs')
+    assert same(R.render_stream(R.Osc('Sine', R.Fixed(np.array([[220]]))), 0, 256, 3, 1), g['sigs/vis_test'])
+    tri = R.Osc('Triangle', R.Fixed(np.array([[440]])))
+    gn = R.Binary('Gain', tri, R.Fixed(np.array([[0.2]])))
+    lp = R.Filter('lp', gn, R.Fixed(np.array([[600]])))
+    m = R.Merge(lp, gn, 1, 1)
+    assert same(R.render_stream(m, 0, 256, 3, 2), g['sigs/lowpass_test'])
+
+
+@pytest.mark.parametrize('tag,pos0', (('p0', 0), ('p1h', HOUR)))
+def test_c2_reduced(golden, tag, pos0):
+    g = golden('c2')
+    o = R.Osc('Sine', R.Fixed(g['c2/hertz']), R.Fixed(g['c2/phase']))
+    f = R.Filter('lp', o, R.Fixed(g['c2/cutoff']))
+    n = R.Binary('Gain', f, R.Fixed(g['c2/gain']))
+    assert same(R.render_stream(n, pos0, 256, 4, 32), g[f'c2/{tag}'])
+
+
+def test_blockloc_table(golden):
+    for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
+        assert R.before(int(pos), int(n), 100) == (bp, bf)
+        assert R.after(int(pos), int(n), 100) == (ap, af)
+        fr = R.frame_range(int(pos), int(n))
+        assert fr.dtype == np.int64 and fr[0, 0] == fr0 and fr[-1, 0] == fr1 and fr.shape == (n, 1)
+
+
+def test_shape_le_doctest_rows():
+    # chain/__init__.py:26-51 (the only behaviour the reference's own doctests pin on this path)
+    s = (10, 2)
+    assert R.shape_le(s, s) and R.shape_le((1, 1), s) and R.shape_le((10, 1), s) and R.shape_le((1, 2), s)
+    assert not R.shape_le((0, 0), s) and not R.shape_le((3, 2), s) and not R.shape_le((10, 0), s)
