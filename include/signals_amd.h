@@ -1,0 +1,106 @@
+/* signals_amd.h -- C ABI of the MI355X (gfx950) block-render kernels.
+ *
+ * The reference (noah-aviel-dove/signals) is 100 % Python: its render path has no FFI.
+ * The functions a native back end has to replace are the numpy/scipy bodies of the
+ * nodes' `_eval` methods; each entry point below names the one it stands in for
+ * (paths relative to /root/reference/src/signals/).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - audio buffers: row-major (frames, channels), channel (= voice) index contiguous,
+ *    `ld` = elements between consecutive rows.  dtype f32 (SIG_F32) by default; every
+ *    entry also accepts f64 (SIG_F64) buffers, which block-rate (frames == 1) control
+ *    requests use.
+ *  - control rows (hertz, phase, cutoff, gain ...): f64, `stride` 1 = one value per voice,
+ *    0 = one scalar broadcast to every voice (a (1,1) reply, chain/__init__.py:59-63).
+ *  - every pointer is a DEVICE pointer; the caller owns all memory; nothing is allocated,
+ *    freed or synchronised inside (safe to capture into a hipGraph).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - return value: 0 on success, otherwise a hipError_t (1 = hipErrorInvalidValue for
+ *    argument errors).  No exceptions cross the boundary.
+ */
+#ifndef SIGNALS_AMD_H
+#define SIGNALS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIG_ABI_VERSION 1
+
+enum { SIG_F32 = 0, SIG_F64 = 1 };
+
+/* oscillator kinds: osc.py:40-62 */
+enum { SIG_OSC_SINE = 0, SIG_OSC_SQUARE = 1, SIG_OSC_SAWTOOTH = 2, SIG_OSC_TRIANGLE = 3 };
+
+/* critical-frequency filter types: fx.py:68-72 (only lp/hp are live in the reference, fx.py:142-151) */
+enum { SIG_FILT_LOWPASS = 0, SIG_FILT_HIGHPASS = 1 };
+
+/* element-wise effects: fx.py:35-60 */
+enum { SIG_EW_GAIN = 0, SIG_EW_MIX = 1, SIG_EW_RINGMOD = 2, SIG_EW_AMP = 3 };
+
+/* bits OR-ed into the optional device status word by kernels (never cleared by them) */
+enum { SIG_STATUS_BAD_CUTOFF = 1 };  /* Wn <= 0 or >= 1: scipy raises ValueError (fx.py:99-102) */
+
+int sig_abi_version(void);
+
+/* Replaces Osc._eval + Sine/Square/Sawtooth/Triangle._osc (osc.py:26-62):
+ *   t[n,v] = (position + n) / rate * hertz[v] + phase[v]      (f64, that operator order)
+ *   out[n,v] = wave_kind(t[n,v])
+ * Position-pure: `rows` may span any number of consecutive blocks.
+ * Square/Sawtooth/Triangle are bit-exact in f64 before the store; Sine is within 1 ulp(f64). */
+int sig_osc_bank(int kind, int64_t position, int32_t rate, int64_t rows, int32_t voices,
+                 const double* hertz, int32_t hertz_stride,
+                 const double* phase, int32_t phase_stride,   /* phase may be NULL = unplugged = 0 */
+                 void* out, int32_t out_dtype, int64_t out_ld, void* stream);
+
+/* Replaces CritFilter._filter + _get_sos (fx.py:85-121) for LowPass/HighPass (order 2 = one
+ * biquad section), batched over `nblocks` consecutive blocks of `block_frames` frames.
+ * For block b (p_b = position + b*block_frames, c_b = min(context, p_b)):
+ *   design butter(2, clip(cutoff[b or 0, v] / (rate/2), 0, 1)) in closed form,
+ *   run the DF2T recurrence in f64 from ZERO state over in rows [b*N - c_b, (b+1)*N),
+ *   store rows [b*N, (b+1)*N).
+ * `in` points at the row aligned with out row 0; `in_history` rows (>= min(context, position))
+ * must precede it in the same allocation (same ld).  The reference's `after` window never
+ * reaches the kept samples (sosfilt is causal) and is not read.
+ * cutoff: (cutoff_blocks, voices) f64 with cutoff_blocks in {1, nblocks}; stride 0/1 as above.
+ * status: optional device int32; SIG_STATUS_BAD_CUTOFF is OR-ed in and the voice's output is NaN. */
+int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
+                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                         const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                         const void* in, int64_t in_ld, int64_t in_history,
+                         void* out, int64_t out_ld, int32_t dtype,
+                         int32_t* status, void* stream);
+
+/* One operand of an element-wise effect.  row_stride / col_stride are in elements; 0 broadcasts
+ * that axis (numpy broadcasting of (1,V), (N,1), (1,1) replies). */
+typedef struct sig_operand {
+    const void* ptr;
+    int64_t row_stride;
+    int32_t col_stride;
+    int32_t dtype;      /* SIG_F32 or SIG_F64 */
+} sig_operand;
+
+/* Replaces Gain/Mix/RingMod/Amp._eval (fx.py:35-60), arithmetic in f64:
+ *   GAIN    out = a * b                       (b = right at block rate)
+ *   MIX     out = c * a + (1 - c) * b         (c = mix at block rate)
+ *   RINGMOD out = a * b
+ *   AMP     out = copysign(a ** b, a)         (NaN for a < 0 with fractional b, like numpy) */
+int sig_elementwise(int op, int64_t rows, int32_t cols,
+                    const sig_operand* a, const sig_operand* b, const sig_operand* c,
+                    void* out, int64_t out_ld, int32_t out_dtype, void* stream);
+
+/* Build-defined sum bus (the reference's Flatten/FlattenUnit crash, shape.py:32-41):
+ *   gains == NULL : out[n,0] = sum_v x[n,v]                          (bus_channels must be 1)
+ *   gains (C,V)   : out[n,c] = sum_v gains[c*gains_ld + v] * x[n,v]
+ * f64 accumulation, fixed summation order (lane-strided, then a butterfly), deterministic. */
+int sig_sum_bus(int64_t rows, int32_t voices, const void* x, int64_t x_ld, int32_t x_dtype,
+                const double* gains, int64_t gains_ld, int32_t bus_channels,
+                void* out, int64_t out_ld, int32_t out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGNALS_AMD_H */

@@ -1,0 +1,48 @@
+"""signals_amd -- MI355X-native block-render engine behind the `signals` node API.
+
+Package root: the three names the render path needs from the reference's package root
+(reference src/signals/__init__.py:15-64) -- `PortName`, `SignalsError`, `SignalFlags` -- without
+the Qt application shell that lives beside them there (out of scope).
+
+`install_as_signals()` aliases this package as `signals` in `sys.modules`, so graph scripts and
+`.sigs` patches that name `signals.chain.osc.Sine` resolve to the classes here unchanged.
+"""
+import enum
+import sys
+
+PortName = str
+
+__all__ = ['PortName', 'SignalsError', 'SignalFlags', 'install_as_signals']
+
+
+class SignalsError(Exception):
+
+    def __str__(self) -> str:
+        return ' '.join((type(self).__name__, *map(str, self.args)))
+
+
+class SignalFlags(enum.Flag):
+    """Node classification bits (reference src/signals/__init__.py:27-58); same names and
+    compositions, so `flags()` results compare equal by name."""
+    CYCLIC = enum.auto()
+    SINK_DEVICE = enum.auto()
+    SOURCE_DEVICE = enum.auto()
+    DEVICE = SINK_DEVICE | SOURCE_DEVICE
+    GENERATOR = enum.auto()
+    EFFECT = enum.auto()
+    AUDIO = GENERATOR | EFFECT | SOURCE_DEVICE
+    EPOCH = enum.auto()
+    RECORDER = enum.auto()
+    VIS = enum.auto()
+    PASSTHRU = enum.auto()
+    SIDE_EFFECT = VIS | RECORDER | PASSTHRU
+
+
+def install_as_signals() -> None:
+    """Make `import signals.chain.osc` (and friends) resolve to this package."""
+    import importlib
+    names = ['', '.discovery', '.chain', '.chain.osc', '.chain.fx', '.chain.fixed', '.chain.noise',
+             '.chain.shape', '.chain.ext', '.chain.driver']
+    for suffix in names:
+        mod = importlib.import_module(__name__ + suffix)
+        sys.modules['signals' + suffix] = mod

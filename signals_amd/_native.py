@@ -1,0 +1,182 @@
+"""ctypes binding of `signals_amd/csrc/libsignals_amd.so` (C ABI: include/signals_amd.h).
+
+torch tensors are the buffer substrate; only their `data_ptr()`, strides and the current HIP stream
+cross the boundary.  There is NO CPU fallback: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import pathlib
+
+import torch
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / 'csrc' / 'libsignals_amd.so'
+
+F32, F64 = 0, 1
+OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
+FILT_TYPES = {'lp': 0, 'hp': 1}
+EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
+STATUS_BAD_CUTOFF = 1
+
+EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus')
+
+
+class NativeError(RuntimeError):
+    """The HIP library is missing, was given a CPU tensor, or returned a hipError_t."""
+
+
+class Operand(ctypes.Structure):
+    _fields_ = [('ptr', ctypes.c_void_p), ('row_stride', ctypes.c_int64),
+                ('col_stride', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              f'(signals_amd/csrc/build.sh).  There is no CPU fallback.')
+        L = ctypes.CDLL(str(LIB_PATH))
+        i32, i64, vp, dp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+        L.sig_abi_version.restype = ctypes.c_int
+        L.sig_abi_version.argtypes = []
+        L.sig_osc_bank.restype = ctypes.c_int
+        L.sig_osc_bank.argtypes = [ctypes.c_int, i64, i32, i64, i32, dp, i32, dp, i32, vp, i32, i64, vp]
+        L.sig_biquad_coldstart.restype = ctypes.c_int
+        L.sig_biquad_coldstart.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, i32,
+                                           vp, i64, i64, vp, i64, i32, vp, vp]
+        L.sig_elementwise.restype = ctypes.c_int
+        L.sig_elementwise.argtypes = [ctypes.c_int, i64, i32, ctypes.POINTER(Operand), ctypes.POINTER(Operand),
+                                      ctypes.POINTER(Operand), vp, i64, i32, vp]
+        L.sig_sum_bus.restype = ctypes.c_int
+        L.sig_sum_bus.argtypes = [i64, i32, vp, i64, i32, dp, i64, i32, vp, i64, i32, vp]
+        if L.sig_abi_version() != 1:
+            raise NativeError('libsignals_amd.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def _check(err: int, what: str) -> None:
+    if err != 0:
+        raise NativeError(f'{what} failed: hipError_t {err}')
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise NativeError(f'unsupported buffer dtype {t.dtype}')
+
+
+def _gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeError('HIP kernels need tensors resident on an MI355X (got a CPU tensor); no CPU fallback')
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ctrl_row(t: torch.Tensor | None, what: str):
+    """(ptr, stride) of an f64 control row shaped (1,V) or (1,1)."""
+    if t is None:
+        return None, 0
+    if t.dtype != torch.float64 or t.dim() != 2 or t.shape[0] != 1 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise NativeError(f'{what}: control rows are contiguous float64 (1,V) or (1,1), got {tuple(t.shape)} {t.dtype}')
+    return t.data_ptr(), (0 if t.shape[1] == 1 else 1)
+
+
+def _audio(t: torch.Tensor, what: str) -> None:
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise NativeError(f'{what}: audio buffers are 2-D with contiguous channels, got strides {t.stride()}')
+
+
+def osc_bank(kind: str, position: int, rate: int, hertz: torch.Tensor, phase: torch.Tensor | None,
+             out: torch.Tensor) -> torch.Tensor:
+    """out[(rows, voices)] <- oscillator `kind` starting at absolute frame `position`."""
+    _gpu(hertz, phase, out)
+    _audio(out, 'osc out')
+    rows, voices = out.shape
+    hp, hs = _ctrl_row(hertz, 'hertz')
+    pp, ps = _ctrl_row(phase, 'phase')
+    for row, name in ((hertz, 'hertz'), (phase, 'phase')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+    _check(lib().sig_osc_bank(OSC_KINDS[kind], position, rate, rows, voices, hp, hs, pp, ps,
+                              out.data_ptr(), _dt(out), out.stride(0), _stream(out)), 'sig_osc_bank')
+    return out
+
+
+def biquad_coldstart(btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                     cutoff: torch.Tensor, buf: torch.Tensor, history: int, out: torch.Tensor,
+                     status: torch.Tensor | None = None) -> torch.Tensor:
+    """`buf` holds `history` context rows followed by nblocks*block_frames input rows;
+    `out` (nblocks*block_frames, voices) receives the filtered blocks.
+    cutoff: f64 (1|nblocks, V|1)."""
+    _gpu(cutoff, buf, out, status)
+    _audio(buf, 'biquad in')
+    _audio(out, 'biquad out')
+    rows, voices = out.shape
+    if rows != block_frames * nblocks or buf.shape[0] != history + rows or buf.shape[1] != voices:
+        raise NativeError(f'biquad shapes: in {tuple(buf.shape)} history {history} out {tuple(out.shape)} '
+                          f'blocks {nblocks}x{block_frames}')
+    if buf.dtype != out.dtype:
+        raise NativeError('biquad in/out dtype differ')
+    if cutoff.dtype != torch.float64 or cutoff.dim() != 2 or not cutoff.is_contiguous():
+        raise NativeError('cutoff must be a contiguous float64 2-D tensor')
+    if cutoff.shape[0] not in (1, nblocks) or cutoff.shape[1] not in (1, voices):
+        raise NativeError(f'cutoff shape {tuple(cutoff.shape)} vs blocks {nblocks} voices {voices}')
+    if cutoff.shape[1] != voices and voices != 1:
+        # the reference indexes crit[0, i] for every channel i (fx.py:99)
+        raise IndexError(f'index {cutoff.shape[1]} is out of bounds for axis 1 with size {cutoff.shape[1]}')
+    in_ptr = buf.data_ptr() + history * buf.stride(0) * buf.element_size()
+    _check(lib().sig_biquad_coldstart(FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
+                                      cutoff.data_ptr(), 0 if cutoff.shape[1] == 1 else 1, cutoff.shape[0],
+                                      in_ptr, buf.stride(0), history, out.data_ptr(), out.stride(0), _dt(out),
+                                      status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_biquad_coldstart')
+    return out
+
+
+def _operand(t: torch.Tensor, rows: int, cols: int, what: str) -> Operand:
+    if t.dim() != 2 or t.shape[0] not in (1, rows) or t.shape[1] not in (1, cols):
+        raise NativeError(f'{what}: shape {tuple(t.shape)} does not broadcast to {(rows, cols)}')
+    rs = 0 if t.shape[0] == 1 else t.stride(0)
+    cs = 0 if t.shape[1] == 1 else t.stride(1)
+    return Operand(t.data_ptr(), rs, cs, _dt(t))
+
+
+def elementwise(op: str, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor | None, out: torch.Tensor) -> torch.Tensor:
+    _gpu(a, b, c, out)
+    _audio(out, 'elementwise out')
+    rows, cols = out.shape
+    A = _operand(a, rows, cols, 'a')
+    B = _operand(b, rows, cols, 'b')
+    C = _operand(c, rows, cols, 'c') if c is not None else None
+    _check(lib().sig_elementwise(EW_OPS[op], rows, cols, ctypes.byref(A), ctypes.byref(B),
+                                 ctypes.byref(C) if C is not None else None,
+                                 out.data_ptr(), out.stride(0), _dt(out), _stream(out)), 'sig_elementwise')
+    return out
+
+
+def sum_bus(x: torch.Tensor, gains: torch.Tensor | None, out: torch.Tensor) -> torch.Tensor:
+    _gpu(x, gains, out)
+    _audio(x, 'bus in')
+    _audio(out, 'bus out')
+    rows, voices = x.shape
+    bus = out.shape[1]
+    if out.shape[0] != rows:
+        raise NativeError('bus rows mismatch')
+    gp, gld = None, 0
+    if gains is not None:
+        if gains.dtype != torch.float64 or gains.dim() != 2 or gains.shape != (bus, voices) or gains.stride(1) != 1:
+            raise NativeError(f'gains must be float64 ({bus},{voices}), got {tuple(gains.shape)} {gains.dtype}')
+        gp, gld = gains.data_ptr(), gains.stride(0)
+    _check(lib().sig_sum_bus(rows, voices, x.data_ptr(), x.stride(0), _dt(x), gp, gld, bus,
+                             out.data_ptr(), out.stride(0), _dt(out), _stream(out)), 'sig_sum_bus')
+    return out

@@ -1,0 +1,67 @@
+"""`Fixed`: constant source -- how per-voice parameters (hertz, cutoff, gain) enter a graph
+(reference src/signals/chain/fixed.py:21-39).  The state value stays a 2-D numpy array so scripts
+(`get_state().value = np.array([[330]])`) and `.sigs` values (`value=[[220]]`, int64) work as they
+are; the device copy is uploaded once and re-uploaded only when the array changes."""
+import attr
+import numpy as np
+import torch
+
+from signals_amd import SignalFlags, runtime
+from signals_amd.chain import (
+    BadStateValue,
+    Emitter,
+    Request,
+    Shape,
+    result_dtype,
+    state,
+)
+
+_WATCH_ELEMS = 1 << 16      # arrays up to this size are compared by value on every reply
+
+
+def _validate_array(instance, attribute, new_value):
+    if not (isinstance(new_value, np.ndarray) and new_value.ndim == 2):
+        raise BadStateValue(instance, attribute.name, new_value, 'must be a 2D array')
+
+
+def _unit_zero() -> np.ndarray:
+    return np.zeros(Shape.unit())
+
+
+class Fixed(Emitter):
+    @state
+    class State(Emitter.State):
+        value: np.ndarray = attr.ib(
+            factory=_unit_zero,
+            validator=_validate_array,
+            on_setattr=attr.setters.validate,
+        )
+
+    def __init__(self):
+        super().__init__()
+        self._resident = None       # (source array, host snapshot, device tensor)
+
+    @classmethod
+    def flags(cls) -> SignalFlags:
+        return super().flags()
+
+    @property
+    def channels(self) -> int:
+        return Shape.of_array(self._state.value).channels
+
+    def resident(self) -> torch.Tensor:
+        """Device copy of `value`: float64 for one-row (control) values -- integers from `.sigs` files
+        are exact below 2**53, like numpy's int64 -> float64 promotion in osc.py:32 -- float32 for
+        multi-row (audio) values."""
+        value = self._state.value
+        held = self._resident
+        if held is not None and held[0] is value and (value.size > _WATCH_ELEMS or np.array_equal(held[1], value)):
+            return held[2]
+        dtype = result_dtype(value.shape[0])
+        host = np.ascontiguousarray(value, dtype=np.float64)
+        tensor = torch.from_numpy(host.copy()).to(device=runtime.device(), dtype=dtype)
+        self._resident = (value, value.copy() if value.size <= _WATCH_ELEMS else None, tensor)
+        return tensor
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        return self.resident()

@@ -1,0 +1,81 @@
+"""Channel-shaping nodes (reference src/signals/chain/shape.py:17-74).  `Merge` works; `Flatten`,
+`FlattenUnit` and `Select` reproduce the reference's behaviour, which is to build a 1-D result and
+fail in the cache write with TypeError -- the usable voice sum is
+`signals_amd.chain.ext.SumBus`."""
+import abc
+
+import attr
+import attrs.validators
+import torch
+
+from signals_amd import SignalFlags
+from signals_amd.chain import (
+    CTRL_DTYPE,
+    BlockCachingEmitter,
+    Receiver,
+    Request,
+    port,
+    state,
+)
+
+
+class Shaper(BlockCachingEmitter, Receiver, abc.ABC):
+
+    @classmethod
+    def flags(cls) -> SignalFlags:
+        return super().flags() | SignalFlags.EFFECT
+
+
+class Scalar(Shaper, abc.ABC):
+    input: Receiver.BoundPort = port('input')
+
+    @property
+    def channels(self) -> int:
+        return 1
+
+
+class Flatten(Scalar):
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        return torch.sum(self.input.forward(request), dim=0)        # 1-D: TypeError downstream
+
+
+class FlattenUnit(Scalar):
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        return torch.mean(self.input.forward(request), dim=0)       # 1-D: TypeError downstream
+
+
+class Select(Scalar):
+    @state
+    class State(BlockCachingEmitter.State):
+        index: int = attr.ib(validator=attrs.validators.ge(0), default=0)
+
+    def _get_result(self, request: Request) -> torch.Tensor:
+        channels = self.input.channels
+        if channels is not None and self._state.index < channels:
+            return super()._get_result(request)
+        return self.empty_result()
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        return self.input.forward(request)[:, self._state.index]   # 1-D: TypeError downstream
+
+
+class Merge(Shaper):
+    """hstack of two inputs, each asked for its own channel count (shape.py:60-74)"""
+
+    @property
+    def channels(self) -> int:
+        return sum(input_.channels for input_ in self.inputs_by_port.values())
+
+    left: Receiver.BoundPort = port('left')
+    right: Receiver.BoundPort = port('right')
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        parts = (self.left.request(request.loc.reslice(self.left.channels)),
+                 self.right.request(request.loc.reslice(self.right.channels)))
+        if parts[0].shape[0] != parts[1].shape[0]:
+            raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
+        if parts[0].dtype != parts[1].dtype:
+            parts = tuple(p.to(CTRL_DTYPE) for p in parts)
+        return torch.cat(parts, dim=1)                              # buffer plumbing, no arithmetic

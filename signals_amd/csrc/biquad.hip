@@ -1,0 +1,183 @@
+// Cold-start Butterworth biquad bank for gfx950.
+// Replaces CritFilter._filter / _get_sos (reference src/signals/chain/fx.py:85-121) for LowPass and
+// HighPass: per voice, per block, design butter(N=2) and run scipy's sosfilt recurrence from ZERO
+// state over [<=100 context frames | block], keeping the block.  The reference re-warms every block
+// (SURVEY.md §0-2), so (voice, block) pairs are independent chains: lanes = voices, and blocks go on
+// the grid.  Coefficients and both state registers stay in f64 VGPRs (f32 recurrence misses the 1e-6
+// bar); HBM storage is f32.
+//
+// Mapping: one wave = 64*VPT consecutive voices of ONE block; each lane walks the rows serially with a
+// U-deep register ring of row loads in flight (each row of a wave is 64 x 4*VPT B contiguous).
+// Algorithmic traffic: 4 B read + 4 B written per voice-sample; the (N+c)/N context re-read is the
+// previous block's tail and is served by L2/Infinity Cache when the neighbouring wave ran recently.
+#include "sig_common.h"
+
+namespace {
+
+constexpr double kPi = 3.141592653589793115997963468544185161590576171875;
+constexpr double kSqrt2 = 1.4142135623730951454746218587388284504413604736328125;
+
+struct Biquad { double b0, b1, b2, a1, a2; };
+
+// Closed form of scipy.signal.butter(2, wn, 'lp'|'hp', output='sos') -- oracle/chain_ref.py:butter2_sos.
+// Returns false (and NaN coefficients) where scipy raises: wn <= 0 or wn >= 1 after the clip (fx.py:99-102).
+__device__ __forceinline__ bool design_butter2(int type, double cutoff, double rate, Biquad& q) {
+    double wn = cutoff / (rate * 0.5);                      // scaled_crit /= rate / 2
+    wn = (wn < 0.0) ? 0.0 : ((wn > 1.0) ? 1.0 : wn);        // clip(0, 1); NaN stays NaN
+    const bool bad = (wn <= 0.0) || (wn >= 1.0);
+    const double k = tan(kPi * wn / 2.0);
+    const double k2 = k * k;
+    const double nrm = 1.0 / (1.0 + kSqrt2 * k + k2);
+    const double nan = __builtin_nan("");
+    if (type == SIG_FILT_LOWPASS) { q.b0 = k2 * nrm; q.b1 = 2.0 * k2 * nrm; q.b2 = q.b0; }
+    else                          { q.b0 = nrm;      q.b1 = -2.0 * nrm;     q.b2 = nrm;  }
+    q.a1 = 2.0 * (k2 - 1.0) * nrm;
+    q.a2 = (1.0 - kSqrt2 * k + k2) * nrm;
+    if (bad) { q.b0 = q.b1 = q.b2 = q.a1 = q.a2 = nan; }
+    return !bad;
+}
+
+template <typename T, int VPT> struct RowVec;
+template <> struct RowVec<float, 1> { using type = float; };
+template <> struct RowVec<double, 1> { using type = double; };
+template <> struct RowVec<float, 4> { using type = float4; };
+template <> struct RowVec<double, 4> { using type = double4; };
+
+template <typename T> __device__ __forceinline__ void unpack(const T& v, double (&x)[1]) { x[0] = (double)v; }
+__device__ __forceinline__ void unpack(const float4& v, double (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+__device__ __forceinline__ void unpack(const double4& v, double (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+__device__ __forceinline__ void pack(float& v, const double (&y)[1]) { v = (float)y[0]; }
+__device__ __forceinline__ void pack(double& v, const double (&y)[1]) { v = y[0]; }
+__device__ __forceinline__ void pack(float4& v, const double (&y)[4]) { v = make_float4((float)y[0], (float)y[1], (float)y[2], (float)y[3]); }
+__device__ __forceinline__ void pack(double4& v, const double (&y)[4]) { v = make_double4(y[0], y[1], y[2], y[3]); }
+
+constexpr int kRing = 8;    // rows of loads in flight per lane
+
+template <typename T, int VPT>
+__global__ __launch_bounds__(256) void biquad_coldstart_kernel(
+    int type, double rate, int64_t position, int N, int K, int ctx, int voices,
+    const double* __restrict__ cutoff, int cs, int cutoff_blocks,
+    const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld,
+    int voice_tiles, int* __restrict__ status)
+{
+    using Vec = typename RowVec<T, VPT>::type;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave = one item
+    const int vt = (int)(item % voice_tiles);
+    const int64_t b = item / voice_tiles;
+    if (b >= K) return;                                                        // wave-uniform
+    const int v0 = (vt * SIG_WAVE + lane) * VPT;
+    const bool live = v0 < voices;                                             // VPT==4 path: voices % 4 == 0
+    const int vc = live ? v0 : 0;                                              // clamp: dead lanes shadow voice 0
+
+    const int64_t p_b = position + b * N;
+    const int c = (int)((p_b < (int64_t)ctx) ? p_b : (int64_t)ctx);            // BlockLoc.before: min(ctx, position)
+
+    Biquad q[VPT];
+    double z0[VPT], z1[VPT];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = (vc + i < voices) ? vc + i : vc;
+        const double hz = cutoff[(cutoff_blocks > 1 ? b * (int64_t)(cs ? voices : 1) : 0) + (int64_t)v * cs];
+        ok &= design_butter2(type, hz, rate, q[i]);
+        z0[i] = 0.0; z1[i] = 0.0;
+    }
+    if (!ok && live && status) atomicOr(status, SIG_STATUS_BAD_CUTOFF);
+
+    const int total = c + N;
+    const T* src = in + (b * N - c) * in_ld + vc;        // first context row of this block
+    T* dst = out + (b * N - c) * out_ld + vc;            // aligned with src; rows < c are never stored
+
+    Vec ring[kRing];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) {
+        const int r = (u < total) ? u : total - 1;
+        ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)r * in_ld);
+    }
+
+    for (int r0 = 0; r0 < total; r0 += kRing) {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {
+            const int r = r0 + u;
+            if (r >= total) break;                                             // wave-uniform
+            double x[VPT], y[VPT];
+            unpack(ring[u], x);
+            const int rn = (r + kRing < total) ? r + kRing : total - 1;        // refill this slot
+            ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * in_ld);
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                // scipy _sosfilt, transposed direct form II, one rounding per op (contract off)
+                y[i] = q[i].b0 * x[i] + z0[i];
+                z0[i] = q[i].b1 * x[i] - q[i].a1 * y[i] + z1[i];
+                z1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
+            }
+            if (r >= c && live) {
+                if (VPT == 4) {
+                    Vec o; pack(o, y);
+                    *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
+                } else {
+                    if (v0 < voices) { Vec o; pack(o, y); *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o; }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K, int32_t ctx, int32_t voices,
+                  const double* cutoff, int32_t cs, int32_t cutoff_blocks,
+                  const T* in, int64_t in_ld, T* out, int64_t out_ld, int32_t* status, hipStream_t stream)
+{
+    const bool vec4 = (voices % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(in) % (4 * sizeof(T)) == 0) &&
+                      (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
+    const int span = SIG_WAVE * (vec4 ? 4 : 1);
+    const int voice_tiles = (voices + span - 1) / span;
+    const int64_t items = (int64_t)voice_tiles * K;
+    const int64_t nwg = (items + 3) / 4;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (vec4)
+        biquad_coldstart_kernel<T, 4><<<(unsigned)nwg, 256, 0, stream>>>(
+            type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld,
+            voice_tiles, status);
+    else
+        biquad_coldstart_kernel<T, 1><<<(unsigned)nwg, 256, 0, stream>>>(
+            type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld,
+            voice_tiles, status);
+    return sig_launch_status();
+}
+
+}  // namespace
+
+extern "C" int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
+                                    int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                    const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                                    const void* in, int64_t in_ld, int64_t in_history,
+                                    void* out, int64_t out_ld, int32_t dtype,
+                                    int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(type == SIG_FILT_LOWPASS || type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(cutoff != nullptr && in != nullptr && out != nullptr);
+    SIG_CHECK_ARG(cutoff_stride == 0 || cutoff_stride == 1);
+    SIG_CHECK_ARG(cutoff_blocks == 1 || cutoff_blocks == nblocks);
+    SIG_CHECK_ARG(in_ld >= voices && out_ld >= voices);
+    // block 0 reads min(context, position) rows in front of `in`; later blocks reach back into
+    // earlier blocks' rows and, when block_frames < context, also into the history.
+    {
+        const int64_t c0 = position < context ? position : context;
+        SIG_CHECK_ARG(in_history >= c0);
+    }
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SIG_F32)
+        return launch_biquad<float>(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride,
+                                    cutoff_blocks, static_cast<const float*>(in), in_ld, static_cast<float*>(out), out_ld,
+                                    status, s);
+    if (dtype == SIG_F64)
+        return launch_biquad<double>(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride,
+                                     cutoff_blocks, static_cast<const double*>(in), in_ld, static_cast<double*>(out), out_ld,
+                                     status, s);
+    return (int)hipErrorInvalidValue;
+}

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build the gfx950 kernel library in-tree.  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off : a*b+c stays two roundings (numpy/scipy operator order); fused ops are written fma().
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function"
+OBJS=()
+for f in *.hip; do
+  o="${f%.hip}.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ sig_common.h -nt "$o" ] || [ ../../include/signals_amd.h -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+  fi
+  OBJS+=("$o")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libsignals_amd.so "${OBJS[@]}"
+echo "built $(pwd)/libsignals_amd.so"
