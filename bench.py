@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered Msamples/s (voice-samples per wall second), 48 kHz, 256-frame blocks.
+
+Workload (BASELINE.json configs[1]): per GPU a 1024-voice
+`Fixed -> Sine -> LowPass -> Gain -> SumBus(stereo)` graph built through the node API and rendered by
+the batched engine, one step = one batch of `--blocks` consecutive 256-frame blocks of synthetic
+parameters (numpy default_rng(0): hertz U(55,1760), phase U(0,1), cutoff U(200,8000), gain U(0,1)/V,
+pan theta U(0,pi/2)), already resident in HBM.  With N > 1 GPUs every rank renders its own 1024 voices
+(weak scaling, no data-path traffic) and the stereo bus is summed across ranks with one RCCL
+all-reduce per batch (the path's only exchange step).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--voices V] [--frames F]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (HIP events around every launch, on the launch stream) and `cpu_baseline` (the CPU oracle,
+structured like the reference: per-channel butter + sosfilt per block, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RATE = 48000
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+# algorithmic HBM bytes per voice-sample, f32 storage, every node output written once and read once
+# per consumer (SURVEY.md §8d, C2 = 24 B over the four kernels)
+ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4}
+
+
+def synth_params(total_voices: int):
+    rng = np.random.default_rng(0)
+    hertz = rng.uniform(55, 1760, size=(1, total_voices))
+    phase = rng.uniform(0, 1, size=(1, total_voices))
+    cutoff = rng.uniform(200, 8000, size=(1, total_voices))
+    gain = rng.uniform(0, 1, size=(1, total_voices)) / total_voices
+    theta = rng.uniform(0, np.pi / 2, size=total_voices)
+    pan = np.stack([np.cos(theta), np.sin(theta)])
+    return dict(hertz=hertz, phase=phase, cutoff=cutoff, gain=gain, pan=pan)
+
+
+def build_graph(p, lo, hi):
+    from signals_amd.chain.ext import SumBus
+    from signals_amd.chain.fixed import Fixed
+    from signals_amd.chain.fx import Gain, LowPass
+    from signals_amd.chain.osc import Sine
+
+    def fixed(v):
+        f = Fixed()
+        f.get_state().value = np.ascontiguousarray(v)
+        return f
+
+    osc = Sine()
+    osc.hertz = fixed(p['hertz'][:, lo:hi])
+    osc.phase = fixed(p['phase'][:, lo:hi])
+    lp = LowPass()
+    lp.input = osc
+    lp.cutoff = fixed(p['cutoff'][:, lo:hi])
+    g = Gain()
+    g.left = lp
+    g.right = fixed(p['gain'][:, lo:hi])
+    bus = SumBus()
+    bus.input = g
+    bus.get_state().gains = np.ascontiguousarray(p['pan'][:, lo:hi])
+    return bus
+
+
+def cpu_baseline(p, voices, frames, budget_s=12.0):
+    """The reference's CPU path as restated by the oracle (pull protocol, per-channel butter+sosfilt per
+    block, block caches, after-windows), single thread, on as many consecutive blocks as fit the budget."""
+    from oracle import chain_ref as R
+    import warnings
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    sl = slice(0, voices)
+    node = R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(p['hertz'][:, sl]), R.Fixed(p['phase'][:, sl])),
+                                     R.Fixed(p['cutoff'][:, sl])), R.Fixed(p['gain'][:, sl]))
+    pan = p['pan'][:, sl]
+    t0 = time.perf_counter()
+    blocks = 0
+    while True:
+        R.sum_bus(R.render(node, blocks * frames, frames, voices, RATE), pan)
+        blocks += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or blocks >= 64:
+            break
+    return dict(value=voices * frames * blocks / dt / 1e6, unit='Msamples/s', cores=1, kind='port',
+                sample=f'{blocks} consecutive {frames}-frame blocks of the {voices}-voice C2 graph from position 0, '
+                       f'{dt:.1f} s, oracle/chain_ref.py (numpy {np.__version__}, scipy butter+sosfilt per channel per block), '
+                       f'host has {os.cpu_count()} logical cores')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--blocks', type=int, default=256, help='256-frame blocks per batch (one step)')
+    ap.add_argument('--voices', type=int, default=1024, help='voices per GPU')
+    ap.add_argument('--frames', type=int, default=256)
+    ap.add_argument('--position', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+
+    from signals_amd import _native, runtime
+    runtime.set_device(f'cuda:{local_rank}')
+    _native.lib()
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N, K = args.voices, args.frames, args.blocks
+    params = synth_params(V * world)
+    timer = None if args.no_kernel_timing else KernelTimer()
+    renderer = BatchRenderer(build_graph(params, rank * V, (rank + 1) * V), channels=2, rate=RATE, timer=timer)
+
+    pos = args.position
+
+    def step():
+        nonlocal pos
+        bus = renderer.render(pos, N, K)                 # (K*N, 2) f32 on this GPU
+        if world > 1:
+            dist.all_reduce(bus)                         # RCCL sum of the stereo bus over xGMI
+        pos += N * K
+        return bus
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if timer:
+        timer.reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bus = step()
+    fence()
+    dt = time.perf_counter() - t0
+    runtime.check_status()
+    assert torch.isfinite(bus).all()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples = V * world * N * K * args.steps
+        line = {
+            'metric': 'rendered Msamples/s (48 kHz, 256-sample blocks)',
+            'value': samples / dt / 1e6,
+            'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'C2: {V}-voice Fixed->Sine->LowPass->Gain->SumBus(stereo) per GPU, 48 kHz, '
+                                   f'{N}-frame blocks, {K} blocks per batch, node-materialised engine (f32 storage, '
+                                   f'f64 phase/recurrence)',
+                       'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
+                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL all-reduce of the stereo bus'},
+        }
+        if timer:
+            summ = timer.summary()
+            total_ms = sum(e['ms'] for e in summ.values())
+            kernels = {}
+            for name, e in summ.items():
+                fam = name.split('[')[0]
+                bpu = ALGO_BYTES.get(fam, 0)
+                avg_ms = e['ms'] / e['calls']
+                kernels[name] = {'calls': e['calls'], 'avg_ms': avg_ms, 'share': e['ms'] / total_ms,
+                                 'algo_GBs': bpu * (e['units'] / e['calls']) / (avg_ms * 1e-3) / 1e9}
+            dom = max(summ, key=lambda k: summ[k]['ms'])
+            traffic = None
+            tfile = ROOT / 'profiles' / 'traffic.json'
+            if tfile.exists():
+                traffic = json.loads(tfile.read_text()).get(dom.split('[')[0])
+            line['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['algo_GBs'],
+                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['algo_GBs'] / HBM_PEAK_GBS,
+                                'traffic': traffic,
+                                'algo_bytes_per_voice_sample': ALGO_BYTES.get(dom.split('[')[0]),
+                                'avg_launch_ms': kernels[dom]['avg_ms']}
+            line['kernels'] = kernels
+            line['pipeline_algo_GBs'] = 24 * samples / world / dt / 1e9
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(params, V, N)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -100,6 +100,13 @@ int sig_sum_bus(int64_t rows, int32_t voices, const void* x, int64_t x_ld, int32
                 const double* gains, int64_t gains_ld, int32_t bus_channels,
                 void* out, int64_t out_ld, int32_t out_dtype, void* stream);
 
+/* Replaces White._eval (noise.py:22-23: np.random.rand(frames, channels), uniform [0,1), global
+ * unseeded RNG -- not reproducible, so parity is statistical only).  Here the value of sample
+ * (position + n, channel) is a counter-based hash of (seed, frame, channel): position-pure and
+ * reproducible; 24 random mantissa bits, u = k * 2^-24, k in [0, 2^24). */
+int sig_white_noise(uint64_t seed, int64_t position, int64_t rows, int32_t channels,
+                    void* out, int32_t out_dtype, int64_t out_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

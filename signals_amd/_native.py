@@ -18,7 +18,8 @@ FILT_TYPES = {'lp': 0, 'hp': 1}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
-EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus')
+EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
+           'sig_white_noise')
 
 
 class NativeError(RuntimeError):
@@ -53,6 +54,8 @@ def lib() -> ctypes.CDLL:
                                       ctypes.POINTER(Operand), vp, i64, i32, vp]
         L.sig_sum_bus.restype = ctypes.c_int
         L.sig_sum_bus.argtypes = [i64, i32, vp, i64, i32, dp, i64, i32, vp, i64, i32, vp]
+        L.sig_white_noise.restype = ctypes.c_int
+        L.sig_white_noise.argtypes = [ctypes.c_uint64, i64, i64, i32, vp, i32, i64, vp]
         if L.sig_abi_version() != 1:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -179,4 +182,12 @@ def sum_bus(x: torch.Tensor, gains: torch.Tensor | None, out: torch.Tensor) -> t
         gp, gld = gains.data_ptr(), gains.stride(0)
     _check(lib().sig_sum_bus(rows, voices, x.data_ptr(), x.stride(0), _dt(x), gp, gld, bus,
                              out.data_ptr(), out.stride(0), _dt(out), _stream(out)), 'sig_sum_bus')
+    return out
+
+
+def white_noise(seed: int, position: int, out: torch.Tensor) -> torch.Tensor:
+    _gpu(out)
+    _audio(out, 'noise out')
+    _check(lib().sig_white_noise(seed, position, out.shape[0], out.shape[1], out.data_ptr(), _dt(out),
+                                 out.stride(0), _stream(out)), 'sig_white_noise')
     return out

@@ -1,0 +1,318 @@
+"""Batched block renderer: K consecutive blocks of a node graph per kernel launch.
+
+The eager pull path (`signals_amd.chain`) mirrors the reference one request at a time; at 1 MiB per
+1024x256 buffer that is launch-bound.  Because oscillators are closed-form in position
+and every filter block cold-starts from zero state <=100 frames early, the K
+blocks of a stream are independent given each filter input's history rows, so one launch per node can
+cover all of them.  `BatchRenderer.render` returns exactly what K sequential `request()` calls
+through the eager path return (tests/test_gpu_engine.py), including the cache-history semantics of
+cascaded filters:
+
+  * a filter's context rows for block b>0 are its input's rows of block b-1 (what the reference's
+    block cache serves by slicing the previous block, chain/__init__.py:431-442);
+  * for block 0 of a continuing stream they are the input's saved tail of the previous batch;
+  * on a fresh start at position p>0 they are the input rendered as its own block [p-c, p), which
+    cold-starts an upstream filter at p-c-100 -- the reference's behaviour on a fresh graph.
+
+The reference's `after(100)` requests never reach kept samples (sosfilt is causal) and, for constant
+block size N > 100, never serve a later request from the cache; they are skipped here.
+
+Graphs that do not fit (control ports driven by anything but `Fixed`, cascaded filters with
+N <= 100, unknown node classes) raise `NotBatchable`; callers fall back to the eager path.
+"""
+from __future__ import annotations
+
+import typing
+
+import torch
+
+from signals_amd import _native, runtime
+from signals_amd.chain import (
+    AUDIO_DTYPE,
+    CTRL_DTYPE,
+    Emitter,
+    Receiver,
+    as_control,
+    broadcast_shape,
+)
+from signals_amd.chain import ext, fixed, fx, noise, osc, shape
+
+CONTEXT = 100
+
+
+class NotBatchable(Exception):
+    """This graph needs the eager pull path."""
+
+
+class KernelTimer:
+    """Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records: list[tuple[str, torch.cuda.Event, torch.cuda.Event, dict]] = []
+
+    def launch(self, name: str, fn: typing.Callable, **meta):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = fn()
+        stop.record()
+        self.records.append((name, start, stop, meta))
+        return out
+
+    def summary(self) -> dict[str, dict]:
+        """call after a device sync"""
+        acc: dict[str, dict] = {}
+        for name, start, stop, meta in self.records:
+            e = acc.setdefault(name, {'calls': 0, 'ms': 0.0, 'units': 0})
+            e['calls'] += 1
+            e['ms'] += start.elapsed_time(stop)
+            e['units'] += meta.get('units', 0)
+        return acc
+
+    def reset(self):
+        self.records.clear()
+
+
+class BatchRenderer:
+
+    def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None):
+        self.node = node
+        self.channels = channels
+        self.rate = rate
+        self.timer = timer
+        self._tails: dict[Emitter, tuple[int, torch.Tensor]] = {}    # node -> (end position, last <=100 rows)
+        self._stream_end: int | None = None
+        self._status: dict[Emitter, runtime.StatusWord] = {}
+
+    # ------------------------------------------------------------------ public
+    def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
+        """Rows = nblocks*block_frames frames from `position`; same values as nblocks sequential
+        eager requests of `block_frames` frames."""
+        if block_frames < 2:
+            raise NotBatchable('block-rate (frames == 1) requests go through the eager path')
+        continuing = self._stream_end == position and bool(self._tails)
+        if not continuing:
+            self._tails.clear()
+        batch = _Batch(self, position, block_frames, nblocks, continuing)
+        out = batch.buffer(self.node, self.channels, 0)
+        for node, buf in batch.impure_outputs():
+            keep = min(CONTEXT, buf.shape[0])
+            self._tails[node] = (position + block_frames * nblocks, buf[buf.shape[0] - keep:].clone())
+        self._stream_end = position + block_frames * nblocks
+        return out
+
+    def reset(self) -> None:
+        self._tails.clear()
+        self._stream_end = None
+
+    # ------------------------------------------------------------------ kernel launch helper
+    def _launch(self, name: str, fn: typing.Callable, **meta):
+        if self.timer is not None:
+            return self.timer.launch(name, fn, **meta)
+        return fn()
+
+    def _status_word(self, node: Emitter) -> torch.Tensor:
+        word = self._status.get(node)
+        if word is None:
+            word = self._status[node] = runtime.StatusWord(node.cls_name())
+        return word.tensor
+
+
+def _is_pure(node: Emitter | None, memo: dict) -> bool:
+    """position-pure: no filter anywhere upstream, so any row range can be rendered in one launch"""
+    if node is None:
+        return True
+    if node not in memo:
+        memo[node] = True       # cycles are rejected elsewhere
+        if isinstance(node, fx.CritFilter):
+            memo[node] = False
+        elif isinstance(node, Receiver):
+            memo[node] = all(_is_pure(up, memo) for up in node.inputs_by_port.values())
+    return memo[node]
+
+
+class _Batch:
+    """One render call: position, N, K fixed; buffers memoised per (node, channels)."""
+
+    def __init__(self, owner: BatchRenderer, position: int, N: int, K: int, continuing: bool):
+        self.owner = owner
+        self.pos, self.N, self.K = position, N, K
+        self.continuing = continuing
+        self.rate = owner.rate
+        self._pure: dict = {}
+        self._memo: dict[tuple[Emitter, int], tuple[torch.Tensor, int]] = {}
+        self._need: dict[tuple[Emitter, int], int] = {}
+        self._impure: dict[Emitter, torch.Tensor] = {}
+
+    # -------------------------------------------------------------- control rows
+    def _control(self, port: Receiver.BoundPort, what: str) -> torch.Tensor:
+        src = port.sig
+        if src is None or not src.get_state().enabled:
+            return Emitter.empty_result()
+        if isinstance(src, fixed.Fixed):
+            row = src.resident()
+            if row.shape[0] != 1:
+                raise NotBatchable(f'{what}: multi-row Fixed on a control port')
+            return as_control(row)
+        raise NotBatchable(f'{what} is driven by {src.cls_name()}; only Fixed control sources are batched')
+
+    # -------------------------------------------------------------- history requirements
+    def _require(self, node: Emitter | None, channels: int, hist: int) -> None:
+        """propagate how many history rows each (node, channels) buffer must carry"""
+        if node is None:
+            return
+        key = (node, channels)
+        if self._need.get(key, -1) >= hist:
+            return
+        self._need[key] = hist
+        if not node.get_state().enabled:
+            return
+        if isinstance(node, fx.CritFilter):
+            self._require(node.input.sig, channels, min(CONTEXT, self.pos))
+        elif isinstance(node, (fx.Mix, fx.RingMod)):
+            self._require(node.left.sig, channels, hist)
+            self._require(node.right.sig, channels, hist)
+        elif isinstance(node, (fx.Gain, fx.Amp)):
+            self._require(node.left.sig, channels, hist)
+        elif isinstance(node, ext.SumBus):
+            self._require(node.input.sig, node.input.channels, hist)
+        elif isinstance(node, shape.Merge):
+            self._require(node.left.sig, node.left.channels, hist)
+            self._require(node.right.sig, node.right.channels, hist)
+
+    # -------------------------------------------------------------- buffers
+    def buffer(self, node: Emitter | None, channels: int, hist: int) -> torch.Tensor:
+        """(hist + K*N, C') tensor: rows [hist:] are the K blocks, rows [:hist] the node's reply to a
+        single block request [pos-hist, pos)."""
+        self._require(node, channels, hist)
+        full, have = self._materialise(node, channels)
+        return full[have - hist:] if have != hist else full
+
+    def _materialise(self, node: Emitter | None, channels: int) -> tuple[torch.Tensor, int]:
+        key = (node, channels)
+        if key in self._memo:
+            return self._memo[key]
+        hist = self._need[key] if node is not None else 0
+        rows = hist + self.N * self.K
+        dev = runtime.device()
+        o = self.owner
+        if node is None or not node.get_state().enabled:
+            result = Emitter.empty_result()                       # (1,1) zeros broadcast everywhere
+            self._memo[key] = (result, 0)
+            return self._memo[key]
+
+        if isinstance(node, fixed.Fixed):
+            value = node.resident()
+            if value.shape[0] != 1:
+                raise NotBatchable('multi-row Fixed as an audio source')
+            result = value
+
+        elif isinstance(node, osc.Osc):
+            hertz = self._control(node.hertz, 'hertz')
+            phase = self._control(node.phase, 'phase')
+            _, voices = broadcast_shape((1, 1), hertz.shape, phase.shape)
+            result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
+            start = self.pos - hist
+            o._launch(f'osc_bank[{node.kind()}]',
+                      lambda: _native.osc_bank(node.kind(), start, self.rate, hertz, phase, result),
+                      units=rows * voices)
+
+        elif isinstance(node, noise.White):
+            result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
+            seed, start = node.get_state().seed, self.pos - hist
+            o._launch('white_noise', lambda: _native.white_noise(seed, start, result), units=rows * channels)
+
+        elif isinstance(node, fx.SingleCritFilter):
+            result = self._filter(node, channels, hist, rows)
+
+        elif isinstance(node, fx.CritFilter):
+            raise TypeError('Value after * must be an iterable, not numpy.float64')     # fx.py:99, like eager
+
+        elif isinstance(node, (fx.Mix, fx.RingMod, fx.Gain, fx.Amp)):
+            a = self._operand(node.left, channels, hist)
+            if isinstance(node, (fx.Gain, fx.Amp)):
+                b, c = self._control(node.right, 'right'), None
+            else:
+                b = self._operand(node.right, channels, hist)
+                c = self._control(node.mix, 'mix') if isinstance(node, fx.Mix) else None
+            shapes = [a.shape, b.shape] + ([c.shape] if c is not None else [])
+            r, cols = broadcast_shape(*shapes)
+            if r == 1:
+                result = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
+            else:
+                result = torch.empty((rows, cols), dtype=AUDIO_DTYPE, device=dev)
+            name = type(node).__name__
+            o._launch(f'elementwise[{name}]', lambda: _native.elementwise(name, a, b, c, result),
+                      units=result.shape[0] * cols)
+
+        elif isinstance(node, ext.SumBus):
+            x = self._operand(node.input, node.input.channels, hist)
+            if x.shape[0] == 1:
+                raise NotBatchable('SumBus over a one-row input')
+            gains = node.resident_gains()
+            result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=dev)
+            o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+        elif isinstance(node, shape.Merge):
+            left = self._operand(node.left, node.left.channels, hist)
+            right = self._operand(node.right, node.right.channels, hist)
+            if left.shape[0] != right.shape[0]:
+                raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
+            result = torch.cat((left.to(AUDIO_DTYPE), right.to(AUDIO_DTYPE)), dim=1)
+
+        else:
+            raise NotBatchable(f'no batched schedule for {node.cls_name()}')
+
+        if not _is_pure(node, self._pure) and result.shape[0] > 1:
+            self._impure[node] = result
+        self._memo[key] = (result, hist if result.shape[0] > 1 else 0)
+        return self._memo[key]
+
+    def _operand(self, port: Receiver.BoundPort, channels: int, hist: int) -> torch.Tensor:
+        """an input as rows [pos-hist, pos+K*N) or a one-row broadcast"""
+        full, have = self._materialise(port.sig, channels)
+        if full.shape[0] == 1:
+            return full
+        return full[have - hist:] if have != hist else full
+
+    # -------------------------------------------------------------- filters
+    def _filter(self, node: fx.SingleCritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:
+        o = self.owner
+        N, K, pos = self.N, self.K, self.pos
+        cutoff = self._control(node.cutoff, 'cutoff')
+        c0 = min(CONTEXT, pos)
+        src = node.input.sig
+        pure_in = _is_pure(src, self._pure)
+        if not pure_in and N <= CONTEXT and (K > 1 or self.continuing):
+            raise NotBatchable('cascaded filters with block size <= 100 depend on the after-window cache entries')
+        window, have = self._materialise(src, channels)
+        if window.shape[0] == 1:
+            raise ValueError('filter input answered a single row (unplugged or disabled input)')
+        window = window[have - c0:] if have != c0 else window
+        if window.shape[1] < channels:
+            raise IndexError(f'index {window.shape[1]} is out of bounds for axis 1 with size {window.shape[1]}')
+        if cutoff.shape[1] < channels:
+            raise IndexError(f'index {cutoff.shape[1]} is out of bounds for axis 1 with size {cutoff.shape[1]}')
+        window = window[:, :channels]
+        cutoff = cutoff[:, :channels]
+        if not cutoff.is_contiguous():
+            cutoff = cutoff.contiguous()
+        result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=window.device)
+        main = result[hist:]
+        btype = str(node.type())
+        status = o._status_word(node)
+        o._launch(f'biquad_coldstart[{btype}]',
+                  lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
+                                                   status=status),
+                  units=N * K * channels)
+        if hist:
+            # this filter's own history rows: the previous batch's tail, or a fresh block [pos-hist, pos)
+            tail = o._tails.get(node) if self.continuing else None
+            if tail is not None and tail[0] == pos and tail[1].shape[0] >= hist and tail[1].shape[1] >= channels:
+                result[:hist].copy_(tail[1][tail[1].shape[0] - hist:, :channels])
+            else:
+                sub = _Batch(o, pos - hist, hist, 1, False)
+                result[:hist].copy_(sub.buffer(node, channels, 0))
+        return result
+
+    def impure_outputs(self):
+        return self._impure.items()

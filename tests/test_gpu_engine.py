@@ -1,0 +1,168 @@
+"""GPU parity, batched engine: K blocks per launch must equal K sequential eager requests (and the
+reference's golden streams), including cascade cache-history semantics."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import HOUR, RATE, f32, fix, maxerr, mkosc, stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+    assert torch.cuda.is_available()
+    from signals_amd import _native, runtime
+    runtime.set_device('cuda:0')
+    _native.lib()
+
+
+def batched(node, position, frames, blocks, channels):
+    from signals_amd.engine import BatchRenderer
+    return BatchRenderer(node, channels, RATE).render(position, frames, blocks).cpu().numpy()
+
+
+def c2_graph(g, V=None, bus=False):
+    from signals_amd.chain import ext, fx
+    sl = slice(None) if V is None else slice(0, V)
+    f = fx.LowPass(); f.input = mkosc('Sine', g['c2/hertz'][:, sl], g['c2/phase'][:, sl]); f.cutoff = fix(g['c2/cutoff'][:, sl])
+    n = fx.Gain(); n.left = f; n.right = fix(g['c2/gain'][:, sl])
+    if bus:
+        b = ext.SumBus(); b.input = n
+        return b
+    return n
+
+
+@pytest.mark.parametrize('tag,pos0', (('p0', 0), ('p1h', HOUR)))
+def test_c2_batched_matches_golden_and_eager(golden, tag, pos0):
+    g = golden('c2')
+    got = batched(c2_graph(g), pos0, 256, 4, 32)
+    assert maxerr(got, f32(g[f'c2/{tag}'])) < 2e-8
+    assert np.array_equal(got, stream(c2_graph(g), pos0, 256, 4, 32))      # bitwise vs the eager path
+
+
+def test_single_filter_any_block_size(golden):
+    from signals_amd.chain import fx
+    g = golden('filter')
+
+    def build():
+        f = fx.HighPass(); f.input = mkosc('Sawtooth', g['filt/hertz'], g['filt/phase']); f.cutoff = fix(g['filt/cutoff'])
+        return f
+
+    for pos, n, k in ((0, 64, 5), (37, 33, 7), (100, 256, 3), (HOUR, 1024, 2)):
+        assert np.array_equal(batched(build(), pos, n, k, 16), stream(build(), pos, n, k, 16)), (pos, n, k)
+
+
+@pytest.mark.parametrize('N', (256, 1024))
+def test_cascade_batched(golden, N):
+    from signals_amd.chain import fx
+    c = golden('cascade')
+
+    def build():
+        f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', c['casc/hertz'], c['casc/phase']); f1.cutoff = fix(c['casc/cut1'])
+        f2 = fx.LowPass(); f2.input = f1; f2.cutoff = fix(c['casc/cut2'])
+        return f2
+
+    got = batched(build(), 0, N, 4, 8)
+    assert maxerr(got, f32(c[f'casc/seq_n{N}'])) < 3e-7
+    assert np.array_equal(got, stream(build(), 0, N, 4, 8))
+
+
+def test_cascade_continuing_batches_and_fresh_start(golden):
+    from signals_amd.chain import fx
+    from signals_amd.engine import BatchRenderer
+    c = golden('cascade')
+
+    def build(second='LowPass'):
+        f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', c['casc/hertz'], c['casc/phase']); f1.cutoff = fix(c['casc/cut1'])
+        f2 = getattr(fx, second)(); f2.input = f1; f2.cutoff = fix(c['casc/cut2'])
+        return f2
+
+    r = BatchRenderer(build(), 8, RATE)
+    parts = [r.render(0, 256, 1), r.render(256, 256, 2), r.render(768, 256, 1)]      # tails carried across batches
+    got = torch.cat(parts).cpu().numpy()
+    assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
+    assert np.array_equal(got, stream(build(), 0, 256, 4, 8))
+    # fresh graph straight at 768: inner filter's history cold-starts at 568 (casc/fresh_p768)
+    fresh = batched(build('HighPass'), 768, 256, 1, 8)
+    assert maxerr(fresh, f32(c['casc/fresh_p768'])) < 3e-7
+    # three-deep cascade, fresh at a late position, vs a fresh eager graph
+    def deep():
+        f3 = fx.HighPass(); f3.input = build(); f3.cutoff = fix(c['casc/cut1'] * 0.5)
+        return f3
+    assert np.array_equal(batched(deep(), 5000, 256, 3, 8), stream(deep(), 5000, 256, 3, 8))
+
+
+def test_mixed_graph_with_bus_and_merge(golden):
+    from signals_amd.chain import ext, fx, shape
+    g = golden('c2')
+
+    def build():
+        gain = c2_graph(g)
+        rm = fx.RingMod(); rm.left = gain; rm.right = mkosc('Triangle', g['c2/hertz'] * 0.01, g['c2/phase'])
+        mx = fx.Mix(); mx.left = rm; mx.right = gain; mx.mix = fix([[0.25]])
+        pan = np.random.default_rng(3).uniform(0, np.pi / 2, 32)
+        bus = ext.SumBus(); bus.input = mx; bus.get_state().gains = np.stack([np.cos(pan), np.sin(pan)])
+        mono = ext.SumBus(); mono.input = gain
+        m = shape.Merge(); m.left = bus; m.right = mono
+        return m
+
+    got = batched(build(), 512, 256, 3, 3)
+    assert got.shape == (768, 3)
+    assert np.array_equal(got, stream(build(), 512, 256, 3, 3))
+
+
+def test_c2_bus_vs_oracle_float64(golden):
+    from oracle import chain_ref as R
+    g = golden('c2')
+    ref = R.sum_bus(g['c2/p0'])
+    got = batched(c2_graph(g, bus=True), 0, 256, 4, 1)
+    assert maxerr(got, f32(ref)) < 2e-8
+
+
+def test_not_batchable_falls_back(golden):
+    from signals_amd.chain import fx
+    from signals_amd.chain.driver import BlockDriver
+    from signals_amd.engine import BatchRenderer, NotBatchable
+    g = golden('c2')
+    lfo = mkosc('Sine', [[2.0]])
+    f = fx.LowPass(); f.input = mkosc('Sine', g['c2/hertz'], g['c2/phase'])
+    scaled = fx.Gain(); scaled.left = lfo; scaled.right = fix([[500.0]])
+    off = fx.Mix(); off.left = scaled; off.right = fix([[4000.0]]); off.mix = fix([[0.5]])
+    f.cutoff = off      # cutoff driven by an oscillator: eager only
+    # one-channel control rows do not index per voice in the reference either (IndexError) -> use 1 voice
+    f1 = fx.LowPass(); f1.input = mkosc('Sine', [[440.0]]); f1.cutoff = off
+    with pytest.raises(NotBatchable):
+        BatchRenderer(f1, 1, RATE).render(0, 256, 2)
+    d = BlockDriver(); d.input = f1
+    a = d.render(3)
+    d2 = BlockDriver(); d2.input = f1
+    b = np.concatenate([d2.pull() for _ in range(3)])
+    assert a.shape == (768, 1) and np.array_equal(a, b)
+
+
+def test_driver_steps_like_the_callback(golden):
+    from signals_amd.chain.driver import BlockDriver
+    g = golden('c2')
+    d = BlockDriver(blocksize=256); d.input = c2_graph(g, bus=True)
+    out = d.render(4)
+    assert d.frame_position == 1024 and d.tell() == 4 and out.shape == (1024, 1)
+    d.seek(0)
+    assert np.array_equal(out[:256], d.pull())
+    stereo = BlockDriver(); stereo.get_state().channels = 2; stereo.input = c2_graph(g, bus=True)
+    s = stereo.render(1)
+    assert s.shape == (256, 2) and np.array_equal(s[:, 0], s[:, 1])       # (N,1) reply broadcast to 2 channels
+
+
+def test_white_noise_statistics():
+    from signals_amd.chain.noise import White
+    from helpers import render
+    w = White(); w.get_state().channels = 64
+    x = render(w, 0, 4096, 64).astype(np.float64)
+    assert x.min() >= 0.0 and x.max() < 1.0
+    assert abs(x.mean() - 0.5) < 5e-3 and abs(x.var() - 1 / 12) < 2e-3
+    assert abs(np.corrcoef(x[:-1].ravel(), x[1:].ravel())[0, 1]) < 0.01
+    assert abs(np.corrcoef(x[:, :-1].ravel(), x[:, 1:].ravel())[0, 1]) < 0.01
+    w2 = White(); w2.get_state().channels = 64
+    assert np.array_equal(render(w2, 1000, 96, 64), x[1000:1096].astype(np.float32))       # position-pure
+    assert np.array_equal(batched(w2, 0, 256, 16, 64), x.astype(np.float32))
