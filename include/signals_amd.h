@@ -50,7 +50,8 @@ int sig_abi_version(void);
  *   t[n,v] = (position + n) / rate * hertz[v] + phase[v]      (f64, that operator order)
  *   out[n,v] = wave_kind(t[n,v])
  * Position-pure: `rows` may span any number of consecutive blocks.
- * Square/Sawtooth/Triangle are bit-exact in f64 before the store; Sine is within 1 ulp(f64). */
+ * Square/Sawtooth/Triangle are bit-exact in f64 before the store.  Sine: f64 store within 1 ulp(f64)
+ * (f64 polynomial); f32 store within 1.3e-7 (exact f64 phase reduction, then v_sin_f32). */
 int sig_osc_bank(int kind, int64_t position, int32_t rate, int64_t rows, int32_t voices,
                  const double* hertz, int32_t hertz_stride,
                  const double* phase, int32_t phase_stride,   /* phase may be NULL = unplugged = 0 */

@@ -10,6 +10,8 @@
 // U-deep register ring of row loads in flight (each row of a wave is 64 x 4*VPT B contiguous).
 // Algorithmic traffic: 4 B read + 4 B written per voice-sample; the (N+c)/N context re-read is the
 // previous block's tail and is served by L2/Infinity Cache when the neighbouring wave ran recently.
+#include <cstdlib>
+
 #include "sig_common.h"
 
 namespace {
@@ -40,10 +42,16 @@ __device__ __forceinline__ bool design_butter2(int type, double cutoff, double r
 template <typename T, int VPT> struct RowVec;
 template <> struct RowVec<float, 1> { using type = float; };
 template <> struct RowVec<double, 1> { using type = double; };
+template <> struct RowVec<float, 2> { using type = float2; };
+template <> struct RowVec<double, 2> { using type = double2; };
 template <> struct RowVec<float, 4> { using type = float4; };
 template <> struct RowVec<double, 4> { using type = double4; };
 
 template <typename T> __device__ __forceinline__ void unpack(const T& v, double (&x)[1]) { x[0] = (double)v; }
+__device__ __forceinline__ void unpack(const float2& v, double (&x)[2]) { x[0] = v.x; x[1] = v.y; }
+__device__ __forceinline__ void unpack(const double2& v, double (&x)[2]) { x[0] = v.x; x[1] = v.y; }
+__device__ __forceinline__ void pack(float2& v, const double (&y)[2]) { v = make_float2((float)y[0], (float)y[1]); }
+__device__ __forceinline__ void pack(double2& v, const double (&y)[2]) { v = make_double2(y[0], y[1]); }
 __device__ __forceinline__ void unpack(const float4& v, double (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
 __device__ __forceinline__ void unpack(const double4& v, double (&x)[4]) { x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
 __device__ __forceinline__ void pack(float& v, const double (&y)[1]) { v = (float)y[0]; }
@@ -51,9 +59,7 @@ __device__ __forceinline__ void pack(double& v, const double (&y)[1]) { v = y[0]
 __device__ __forceinline__ void pack(float4& v, const double (&y)[4]) { v = make_float4((float)y[0], (float)y[1], (float)y[2], (float)y[3]); }
 __device__ __forceinline__ void pack(double4& v, const double (&y)[4]) { v = make_double4(y[0], y[1], y[2], y[3]); }
 
-constexpr int kRing = 8;    // rows of loads in flight per lane
-
-template <typename T, int VPT>
+template <typename T, int VPT, int kRing>   // kRing = rows of loads in flight per lane
 __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
     int type, double rate, int64_t position, int N, int K, int ctx, int voices,
     const double* __restrict__ cutoff, int cs, int cutoff_blocks,
@@ -113,15 +119,17 @@ __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
                 z1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
             }
             if (r >= c && live) {
-                if (VPT == 4) {
-                    Vec o; pack(o, y);
-                    *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
-                } else {
-                    if (v0 < voices) { Vec o; pack(o, y); *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o; }
-                }
+                Vec o; pack(o, y);
+                *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
             }
         }
     }
+}
+
+static int biquad_variant() {
+    // tuning hook: SIG_BIQUAD_VARIANT=<vpt><ring> e.g. "416" = 4 voices/lane, 16-row ring
+    static int v = [] { const char* e = getenv("SIG_BIQUAD_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 template <typename T>
@@ -129,22 +137,35 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
                   const double* cutoff, int32_t cs, int32_t cutoff_blocks,
                   const T* in, int64_t in_ld, T* out, int64_t out_ld, int32_t* status, hipStream_t stream)
 {
-    const bool vec4 = (voices % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) &&
-                      (reinterpret_cast<uintptr_t>(in) % (4 * sizeof(T)) == 0) &&
-                      (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0);
-    const int span = SIG_WAVE * (vec4 ? 4 : 1);
+    auto ok = [&](int vpt) {
+        return (voices % vpt == 0) && (in_ld % vpt == 0) && (out_ld % vpt == 0) &&
+               (reinterpret_cast<uintptr_t>(in) % (vpt * sizeof(T)) == 0) &&
+               (reinterpret_cast<uintptr_t>(out) % (vpt * sizeof(T)) == 0);
+    };
+    int variant = biquad_variant();
+    int vpt = variant ? variant / 100 : 4;
+    int ring = variant ? variant % 100 : 8;
+    if (!ok(vpt)) { vpt = 1; ring = 8; }
+    const int span = SIG_WAVE * vpt;
     const int voice_tiles = (voices + span - 1) / span;
     const int64_t items = (int64_t)voice_tiles * K;
     const int64_t nwg = (items + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    if (vec4)
-        biquad_coldstart_kernel<T, 4><<<(unsigned)nwg, 256, 0, stream>>>(
-            type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld,
-            voice_tiles, status);
-    else
-        biquad_coldstart_kernel<T, 1><<<(unsigned)nwg, 256, 0, stream>>>(
-            type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld,
-            voice_tiles, status);
+#define SIG_BQ(V, R) biquad_coldstart_kernel<T, V, R><<<(unsigned)nwg, 256, 0, stream>>>( \
+        type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld, voice_tiles, status)
+    switch (vpt * 100 + ring) {
+        case 108: SIG_BQ(1, 8); break;
+        case 116: SIG_BQ(1, 16); break;
+        case 132: SIG_BQ(1, 32); break;
+        case 208: SIG_BQ(2, 8); break;
+        case 216: SIG_BQ(2, 16); break;
+        case 232: SIG_BQ(2, 32); break;
+        case 408: SIG_BQ(4, 8); break;
+        case 416: SIG_BQ(4, 16); break;
+        case 432: SIG_BQ(4, 32); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef SIG_BQ
     return sig_launch_status();
 }
 

@@ -4,8 +4,8 @@ node API (one HIP kernel per node per block, through the C ABI) against the refe
 Tolerances (BASELINE.json north_star: 1e-6 in float32, integer positions bit-exact):
   * Square/Sawtooth/Triangle: BIT-EXACT against float32(reference float64) -- their f64 arithmetic is
     reproduced operation for operation;
-  * Sine: <= 1 float32 ulp (6e-8 at |y|~1): the f64 value differs from libm's by ~1e-16, which can flip
-    a float32 rounding tie;
+  * Sine, float32 store: <= 1.5e-7 (exact f64 phase reduction, then the hardware v_sin_f32);
+    float64 (block-rate) store: 1e-15 (f64 polynomial);
   * block-rate (float64) replies: 1e-15;
   * filters/effects on float32 buffers: 1e-6 bar, 3e-7 asserted.
 """
@@ -18,6 +18,7 @@ from helpers import HOUR, OSC, RATE, f32, fix, loc, maxerr, mkosc, render, strea
 pytestmark = pytest.mark.gpu
 
 ULP1 = 1.2e-7
+SINE_TOL = 1.5e-7      # f32 Sine: exact phase reduction + v_sin_f32 (measured max error 1.07e-7)
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -43,14 +44,13 @@ def test_osc_golden(golden, kind):
         if exact:
             assert np.array_equal(got, ref), (key, maxerr(got, ref))
         else:
-            assert maxerr(got, ref) <= ULP1, key
-            assert np.mean(got != ref) < 0.01, key       # rounding-tie flips are rare
+            assert maxerr(got, ref) <= SINE_TOL, key
 
 
 def test_osc_int_hertz_and_block_rate(golden):
     g = golden('osc')
     got = render(mkosc('Sine', np.array([[220]])), 0, 256, 1)
-    assert maxerr(got, f32(g['osc/int_hertz/Sine'])) <= ULP1
+    assert maxerr(got, f32(g['osc/int_hertz/Sine'])) <= SINE_TOL
     ctrl = render(mkosc('Sine', g['osc/hertz'], g['osc/phase']), 512, 1, 16)
     assert ctrl.dtype == np.float64 and ctrl.shape == (1, 16)
     assert maxerr(ctrl, g['osc/ctrl/Sine/p512']) < 1e-15
@@ -156,13 +156,13 @@ def test_protocol_corners(golden):
     u = render(n, pos, N, V)
     assert u.shape == g['fxs/unplugged_left'].shape and np.array_equal(u, g['fxs/unplugged_left'])
     b = render(mkosc('Sine', [[440.0]]), 0, N, 2)
-    assert b.shape == (N, 1) and maxerr(b, f32(g['fxs/broadcast_1to2'])) <= ULP1
+    assert b.shape == (N, 1) and maxerr(b, f32(g['fxs/broadcast_1to2'])) <= SINE_TOL
 
 
 def test_sigs_topologies(golden):
     from signals_amd.chain import fx, shape
     g = golden('sigs')
-    assert maxerr(stream(mkosc('Sine', np.array([[220]])), 0, 256, 3, 1), f32(g['sigs/vis_test'])) <= ULP1
+    assert maxerr(stream(mkosc('Sine', np.array([[220]])), 0, 256, 3, 1), f32(g['sigs/vis_test'])) <= SINE_TOL
     tri = mkosc('Triangle', np.array([[440]]))
     gn = fx.Gain(); gn.left = tri; gn.right = fix(np.array([[0.2]]))
     lp = fx.LowPass(); lp.input = gn; lp.cutoff = fix(np.array([[600]]))

@@ -117,7 +117,7 @@ def test_c2_bus_vs_oracle_float64(golden):
     g = golden('c2')
     ref = R.sum_bus(g['c2/p0'])
     got = batched(c2_graph(g, bus=True), 0, 256, 4, 1)
-    assert maxerr(got, f32(ref)) < 2e-8
+    assert maxerr(got, f32(ref)) < 1e-7          # 32 voices, each within 1.5e-7 * gain(<=1/32) + bus rounding
 
 
 def test_not_batchable_falls_back(golden):
