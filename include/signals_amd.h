@@ -108,6 +108,21 @@ int sig_sum_bus(int64_t rows, int32_t voices, const void* x, int64_t x_ld, int32
 int sig_white_noise(uint64_t seed, int64_t position, int64_t rows, int32_t channels,
                     void* out, int32_t out_dtype, int64_t out_ld, void* stream);
 
+/* Build-defined ADSR envelope bank (the reference has only a dead sketch, sig.py:89-100):
+ * position-pure piecewise-linear envelope per voice at frame rate; definition in
+ * oracle/chain_ref.py:adsr.  params[6] = device pointers to the f64 rows
+ * {attack, decay, sustain, release, gate_on, gate_off} (seconds; sustain is a level), strides[6]
+ * their 0/1 strides.  `params` and `strides` themselves are HOST arrays. */
+int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices,
+             const double* const* params, const int32_t* strides,
+             void* out, int32_t out_dtype, int64_t out_ld, void* stream);
+
+/* Build-defined dense mix matrix (BASELINE config 5), f32 in/out, exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32):  out[n, 64g:64g+64] = x[n, 64g:64g+64] @ matrix,  matrix (64,64)
+ * row-major contiguous, voices % 64 == 0, x 16-byte aligned with x_ld % 4 == 0. */
+int sig_mix_matrix(int64_t rows, int32_t voices, const float* x, int64_t x_ld,
+                   const float* matrix, float* out, int64_t out_ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

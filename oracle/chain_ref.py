@@ -187,24 +187,32 @@ def sum_bus(x: np.ndarray, gains: np.ndarray | None = None) -> np.ndarray:
 
 def adsr(position: int, frames: int, rate: int, attack, decay, sustain, release, gate_on, gate_off) -> np.ndarray:
     """Build-defined position-pure piecewise-linear envelope, per voice, frame rate.
-    All parameters are (1,V) rows; times in seconds, gate_on/gate_off in seconds from position 0.
-    level(t): 0 before gate_on; 0->1 linearly over `attack`; 1->sustain over `decay`;
-    sustain until gate_off; then the level held at gate_off falls linearly to 0 over `release`.
-    Parity unpinned by the reference (only a dead sketch exists, sig.py:89-100)."""
+    All parameters are (1,V) rows; times in seconds from position 0, sustain a level.
+        t = n / rate;  u = t - gate_on;  v = u - attack;  w = t - gate_off
+        held(t)  = 0 (u < 0) | clip(u * (1/attack), 0, 1) (v < 0) | 1 + (sustain - 1) * clip(v * (1/decay), 0, 1)
+                   (a zero-length stage counts as complete)
+        level(t) = held(t) (w < 0) | held(gate_off) * clip(1 - w * (1/release), 0, 1)   (release == 0: 0)
+    Parity unpinned by the reference (only a dead sketch exists, sig.py:89-100); this restatement is the
+    definition and signals_amd/csrc/adsr.hip follows it operation for operation."""
+    attack, decay, sustain, release, gate_on, gate_off = (
+        np.asarray(a, dtype=np.float64) for a in (attack, decay, sustain, release, gate_on, gate_off))
     t = frame_range(position, frames) / rate
+    with np.errstate(divide='ignore'):
+        ia = np.where(attack > 0, 1.0 / np.where(attack > 0, attack, 1.0), 0.0)
+        id_ = np.where(decay > 0, 1.0 / np.where(decay > 0, decay, 1.0), 0.0)
+        ir = np.where(release > 0, 1.0 / np.where(release > 0, release, 1.0), 0.0)
 
     def held(tt):
         u = tt - gate_on
-        a = np.where(attack > 0, np.clip(u / np.where(attack > 0, attack, 1), 0, 1), (u >= 0) * 1.0)
         v = u - attack
-        d = np.where(decay > 0, np.clip(v / np.where(decay > 0, decay, 1), 0, 1), (v >= 0) * 1.0)
+        a = np.where(ia > 0, np.clip(u * ia, 0.0, 1.0), 1.0)
+        d = np.where(id_ > 0, np.clip(v * id_, 0.0, 1.0), 1.0)
         return np.where(u < 0, 0.0, np.where(v < 0, a, 1.0 + (sustain - 1.0) * d))
 
-    lvl_on = held(t)
-    lvl_at_off = held(gate_off + 0 * t)
+    hold_off = held(gate_off + np.zeros((1, 1)))
     w = t - gate_off
-    r = np.where(release > 0, np.clip(1.0 - w / np.where(release > 0, release, 1), 0, 1), 0.0)
-    return np.where(w < 0, lvl_on, lvl_at_off * r)
+    rel = np.where(ir > 0, np.clip(1.0 - w * ir, 0.0, 1.0), 0.0)
+    return np.where(w < 0, held(t), hold_off * rel)
 
 
 def mix_matrix(x: np.ndarray, m: np.ndarray) -> np.ndarray:

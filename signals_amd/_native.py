@@ -19,7 +19,7 @@ EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
-           'sig_white_noise')
+           'sig_white_noise', 'sig_adsr', 'sig_mix_matrix')
 
 
 class NativeError(RuntimeError):
@@ -56,6 +56,11 @@ def lib() -> ctypes.CDLL:
         L.sig_sum_bus.argtypes = [i64, i32, vp, i64, i32, dp, i64, i32, vp, i64, i32, vp]
         L.sig_white_noise.restype = ctypes.c_int
         L.sig_white_noise.argtypes = [ctypes.c_uint64, i64, i64, i32, vp, i32, i64, vp]
+        L.sig_adsr.restype = ctypes.c_int
+        L.sig_adsr.argtypes = [i64, i32, i64, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                               vp, i32, i64, vp]
+        L.sig_mix_matrix.restype = ctypes.c_int
+        L.sig_mix_matrix.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp]
         if L.sig_abi_version() != 1:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -190,4 +195,35 @@ def white_noise(seed: int, position: int, out: torch.Tensor) -> torch.Tensor:
     _audio(out, 'noise out')
     _check(lib().sig_white_noise(seed, position, out.shape[0], out.shape[1], out.data_ptr(), _dt(out),
                                  out.stride(0), _stream(out)), 'sig_white_noise')
+    return out
+
+
+ADSR_PARAMS = ('attack', 'decay', 'sustain', 'release', 'gate_on', 'gate_off')
+
+
+def adsr(position: int, rate: int, rows: dict, out: torch.Tensor) -> torch.Tensor:
+    """rows: name -> f64 control row (1,V)|(1,1) for each of ADSR_PARAMS"""
+    _gpu(out, *rows.values())
+    _audio(out, 'adsr out')
+    ptrs = (ctypes.c_void_p * 6)()
+    strides = (ctypes.c_int32 * 6)()
+    for i, name in enumerate(ADSR_PARAMS):
+        ptrs[i], strides[i] = _ctrl_row(rows[name], name)
+        if rows[name].shape[1] not in (1, out.shape[1]):
+            raise NativeError(f'{name} has {rows[name].shape[1]} channels for {out.shape[1]} voices')
+    _check(lib().sig_adsr(position, rate, out.shape[0], out.shape[1], ptrs, strides, out.data_ptr(), _dt(out),
+                          out.stride(0), _stream(out)), 'sig_adsr')
+    return out
+
+
+def mix_matrix(x: torch.Tensor, matrix: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _gpu(x, matrix, out)
+    _audio(x, 'mix_matrix in')
+    _audio(out, 'mix_matrix out')
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or matrix.dtype != torch.float32:
+        raise NativeError('mix_matrix is float32 in / float32 out')
+    if matrix.shape != (64, 64) or not matrix.is_contiguous() or x.shape != out.shape or x.shape[1] % 64:
+        raise NativeError(f'mix_matrix shapes: x {tuple(x.shape)} matrix {tuple(matrix.shape)} out {tuple(out.shape)}')
+    _check(lib().sig_mix_matrix(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), matrix.data_ptr(),
+                                out.data_ptr(), out.stride(0), _stream(out)), 'sig_mix_matrix')
     return out

@@ -1,0 +1,114 @@
+// ADSR envelope bank for gfx950 (build-defined node; the reference has only a dead
+// sketch, src/signals/sig.py:89-100).  Position-pure piecewise-linear envelope per voice at frame rate:
+//   t = n / rate;  u = t - gate_on;  v = u - attack;  w = t - gate_off
+//   held(t) = 0                                   (u < 0)
+//           = clip(u * (1/attack), 0, 1)          (v < 0)
+//           = 1 + (sustain - 1) * clip(v * (1/decay), 0, 1)      (a zero-length stage counts as complete)
+//   level(t) = held(t)                            (w < 0)
+//            = held(gate_off) * clip(1 - w * (1/release), 0, 1)  (release == 0: 0)
+// Definition and operator order are those of oracle/chain_ref.py:adsr (f64, contract off), so the f32 store
+// is bit-exact against it.  HBM-write-bound: 4 B per voice-sample, ~12 f64 ops.
+#include "sig_common.h"
+
+namespace {
+
+struct AdsrRows { const double* p[6]; int s[6]; };   // attack, decay, sustain, release, gate_on, gate_off
+
+__device__ __forceinline__ double clip01(double x) { return (x < 0.0) ? 0.0 : ((x > 1.0) ? 1.0 : x); }
+
+struct Voice { double ia, id, sm1, ir, on, off, attack, hold_off; };
+
+__device__ __forceinline__ double held(const Voice& p, double t) {
+    const double u = t - p.on;
+    const double v = u - p.attack;
+    const double a = (p.ia > 0.0) ? clip01(u * p.ia) : 1.0;
+    const double d = (p.id > 0.0) ? clip01(v * p.id) : 1.0;
+    return (u < 0.0) ? 0.0 : ((v < 0.0) ? a : 1.0 + p.sm1 * d);
+}
+
+constexpr int kRowsPerWave = 16;
+
+template <int VEC, typename OUT>
+__global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate, int64_t rows, int voices, AdsrRows in,
+                                                   OUT* __restrict__ out, int64_t ld, int voice_tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const int vt = blockIdx.x % voice_tiles;
+    const int64_t rt = blockIdx.x / voice_tiles;
+    const int v0 = (vt * SIG_WAVE + lane) * VEC;
+    const int64_t r0 = (rt * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (r0 >= rows) return;
+    const double q_lane = (double)(position + r0 + (lane & (kRowsPerWave - 1))) / rate;
+    Voice p[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int v = (v0 + i < voices) ? v0 + i : 0;
+        const double attack = in.p[0][(int64_t)v * in.s[0]], decay = in.p[1][(int64_t)v * in.s[1]];
+        const double sustain = in.p[2][(int64_t)v * in.s[2]], release = in.p[3][(int64_t)v * in.s[3]];
+        p[i].on = in.p[4][(int64_t)v * in.s[4]];
+        p[i].off = in.p[5][(int64_t)v * in.s[5]];
+        p[i].attack = attack;
+        p[i].ia = (attack > 0.0) ? 1.0 / attack : 0.0;
+        p[i].id = (decay > 0.0) ? 1.0 / decay : 0.0;
+        p[i].ir = (release > 0.0) ? 1.0 / release : 0.0;
+        p[i].sm1 = sustain - 1.0;
+        p[i].hold_off = held(p[i], p[i].off);
+    }
+#pragma unroll 2
+    for (int j = 0; j < kRowsPerWave; ++j) {
+        const int64_t row = r0 + j;
+        if (row >= rows) break;
+        const double t = sig_readlane_f64(q_lane, j);
+        OUT y[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const double w = t - p[i].off;
+            const double rel = (p[i].ir > 0.0) ? clip01(1.0 - w * p[i].ir) : 0.0;
+            y[i] = (OUT)((w < 0.0) ? held(p[i], t) : p[i].hold_off * rel);
+        }
+        OUT* dst = out + row * ld + v0;
+        if (VEC == 4) {
+            if (v0 < voices) {
+                typename sig_vec4<OUT>::type o;
+                o.x = y[0]; o.y = y[1]; o.z = y[2]; o.w = y[3];
+                *reinterpret_cast<typename sig_vec4<OUT>::type*>(dst) = o;
+            }
+        } else {
+            if (v0 < voices) dst[0] = y[0];
+        }
+    }
+}
+
+template <typename OUT>
+int launch_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices, const AdsrRows& in, OUT* out, int64_t ld,
+                hipStream_t stream)
+{
+    const bool vec4 = (voices % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(OUT)) == 0);
+    const int span = SIG_WAVE * (vec4 ? 4 : 1);
+    const int voice_tiles = (voices + span - 1) / span;
+    const int64_t nwg = ((rows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave)) * voice_tiles;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (vec4) adsr_kernel<4, OUT><<<(unsigned)nwg, 256, 0, stream>>>(position, (double)rate, rows, voices, in, out, ld, voice_tiles);
+    else adsr_kernel<1, OUT><<<(unsigned)nwg, 256, 0, stream>>>(position, (double)rate, rows, voices, in, out, ld, voice_tiles);
+    return sig_launch_status();
+}
+
+}  // namespace
+
+extern "C" int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices,
+                        const double* const* params, const int32_t* strides,
+                        void* out, int32_t out_dtype, int64_t out_ld, void* stream)
+{
+    SIG_CHECK_ARG(position >= 0 && rate > 0 && rows >= 0 && voices >= 0 && params && strides && out && out_ld >= voices);
+    AdsrRows in;
+    for (int i = 0; i < 6; ++i) {
+        SIG_CHECK_ARG(params[i] != nullptr && (strides[i] == 0 || strides[i] == 1));
+        in.p[i] = params[i];
+        in.s[i] = strides[i];
+    }
+    if (rows == 0 || voices == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == SIG_F32) return launch_adsr<float>(position, rate, rows, voices, in, static_cast<float*>(out), out_ld, s);
+    if (out_dtype == SIG_F64) return launch_adsr<double>(position, rate, rows, voices, in, static_cast<double*>(out), out_ld, s);
+    return (int)hipErrorInvalidValue;
+}

@@ -175,6 +175,8 @@ class _Batch:
             self._require(node.left.sig, channels, hist)
         elif isinstance(node, ext.SumBus):
             self._require(node.input.sig, node.input.channels, hist)
+        elif isinstance(node, ext.MixMatrix):
+            self._require(node.input.sig, channels, hist)
         elif isinstance(node, shape.Merge):
             self._require(node.left.sig, node.left.channels, hist)
             self._require(node.right.sig, node.right.channels, hist)
@@ -251,6 +253,23 @@ class _Batch:
             gains = node.resident_gains()
             result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=dev)
             o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+        elif isinstance(node, ext.ADSR):
+            ctl = node.control_rows(lambda bound: self._control(bound, bound.name))
+            _, voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))
+            result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
+            start = self.pos - hist
+            o._launch('adsr', lambda: _native.adsr(start, self.rate, ctl, result), units=rows * voices)
+
+        elif isinstance(node, ext.MixMatrix):
+            x = self._operand(node.input, channels, hist)
+            if x.shape[0] == 1 or x.shape[1] % 64:
+                raise ValueError(f'MixMatrix needs (rows, 64*g) audio, got {tuple(x.shape)}')
+            if x.dtype != AUDIO_DTYPE or not x.is_contiguous():
+                x = x.to(AUDIO_DTYPE).contiguous()
+            matrix = node.resident_matrix()
+            result = torch.empty_like(x)
+            o._launch('mix_matrix', lambda: _native.mix_matrix(x, matrix, result), units=x.shape[0] * x.shape[1])
 
         elif isinstance(node, shape.Merge):
             left = self._operand(node.left, node.left.channels, hist)

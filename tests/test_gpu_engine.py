@@ -166,3 +166,100 @@ def test_white_noise_statistics():
     w2 = White(); w2.get_state().channels = 64
     assert np.array_equal(render(w2, 1000, 96, 64), x[1000:1096].astype(np.float32))       # position-pure
     assert np.array_equal(batched(w2, 0, 256, 16, 64), x.astype(np.float32))
+
+
+def adsr_rows(V, seed=11):
+    rng = np.random.default_rng(seed)
+    return dict(attack=rng.uniform(0.001, 0.02, (1, V)), decay=rng.uniform(0.001, 0.03, (1, V)),
+                sustain=rng.uniform(0.2, 0.9, (1, V)), release=rng.uniform(0.001, 0.05, (1, V)),
+                gate_on=rng.uniform(0.0, 0.01, (1, V)), gate_off=rng.uniform(0.03, 0.06, (1, V)))
+
+
+def mk_adsr(rows):
+    from signals_amd.chain.ext import ADSR
+    a = ADSR()
+    for k, v in rows.items():
+        setattr(a, k, fix(v))
+    return a
+
+
+def test_adsr_bit_exact_vs_oracle():
+    from oracle import chain_ref as R
+    from helpers import render
+    V = 24
+    rows = adsr_rows(V)
+    rows['attack'][0, 0] = 0.0; rows['decay'][0, 1] = 0.0; rows['release'][0, 2] = 0.0     # zero-length stages
+    rows['gate_off'][0, 3] = rows['gate_on'][0, 3] + 0.5 * rows['attack'][0, 3]             # released mid-attack
+    for pos, n in ((0, 8192), (1000, 777)):
+        got = render(mk_adsr(rows), pos, n, V)
+        ref = R.adsr(pos, n, RATE, **rows)
+        assert got.shape == (n, V) and np.array_equal(got, f32(ref)), (pos, n)
+    env = R.adsr(0, 8192, RATE, **rows)
+    assert env.min() >= 0.0 and env.max() <= 1.0 and env[-1].max() == 0.0 and env.max() > 0.99
+    ctrl = render(mk_adsr(rows), 960, 1, V)
+    assert ctrl.dtype == np.float64 and np.array_equal(ctrl, R.adsr(960, 1, RATE, **rows))
+    assert np.array_equal(batched(mk_adsr(rows), 0, 256, 32, V), f32(env))
+
+
+def test_mix_matrix_mfma_layout_and_values():
+    """A = identity-like probes with an ASYMMETRIC matrix catch row/col swaps in the MFMA fragment maps."""
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((64, 64)) / 8
+    for rows, V in ((32, 64), (77, 128), (256, 4096)):
+        x = rng.standard_normal((rows, V)).astype(np.float32)
+        xt = torch.from_numpy(x).cuda()
+        out = _native.mix_matrix(xt, torch.from_numpy(M.astype(np.float32)).cuda(), torch.empty_like(xt)).cpu().numpy()
+        ref = R.mix_matrix(x.astype(np.float64), M.astype(np.float32).astype(np.float64))
+        assert maxerr(out, ref) < 2e-6, (rows, V)        # 64-term f32 fmaf chain, |x*m| sum ~ 6
+    eye = np.zeros((64, 64), dtype=np.float32); eye[np.arange(64), np.arange(64)] = 1
+    asym = (np.arange(64)[:, None] * 64 + np.arange(64)[None, :]).astype(np.float32)      # exact integers
+    out = _native.mix_matrix(torch.from_numpy(eye).cuda(), torch.from_numpy(asym).cuda(),
+                             torch.empty(64, 64, device='cuda')).cpu().numpy()
+    assert np.array_equal(out, asym)
+
+
+def c3_graph(V, seed=21):
+    """BASELINE config 3: Saw -> LowPass -> LowPass -> (x ADSR) -> SumBus"""
+    from signals_amd.chain import ext, fx
+    rng = np.random.default_rng(seed)
+    p = dict(hertz=rng.uniform(55, 1760, (1, V)), phase=rng.uniform(0, 1, (1, V)),
+             cut1=rng.uniform(200, 8000, (1, V)), cut2=rng.uniform(200, 8000, (1, V)), env=adsr_rows(V, seed))
+    f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', p['hertz'], p['phase']); f1.cutoff = fix(p['cut1'])
+    f2 = fx.LowPass(); f2.input = f1; f2.cutoff = fix(p['cut2'])
+    rm = fx.RingMod(); rm.left = f2; rm.right = mk_adsr(p['env'])
+    bus = ext.SumBus(); bus.input = rm
+    return bus, p
+
+
+def test_c3_config_vs_oracle_and_eager():
+    from oracle import chain_ref as R
+    V, N, K = 16, 1024, 3
+    bus, p = c3_graph(V)
+    got = batched(bus, 0, N, K, 1)
+    o = R.Osc('Sawtooth', R.Fixed(p['hertz']), R.Fixed(p['phase']))
+    f2 = R.Filter('lp', R.Filter('lp', o, R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
+    ref = R.sum_bus(R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, K, V))
+    assert maxerr(got, f32(ref)) < 1e-6
+    assert np.array_equal(got, stream(c3_graph(V)[0], 0, N, K, 1))
+
+
+def test_c5_config_vs_oracle():
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    V, N, K = 128, 256, 2
+    rng = np.random.default_rng(31)
+    hz, ph, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(200, 8000, (1, V))
+    M = np.linalg.qr(rng.standard_normal((64, 64)))[0]
+
+    def build():
+        f = fx.LowPass(); f.input = mkosc('Sine', hz, ph); f.cutoff = fix(cut)
+        mm = ext.MixMatrix(); mm.input = f; mm.get_state().matrix = M
+        return mm
+
+    got = batched(build(), 0, N, K, V)
+    lp = R.render_stream(R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), R.Fixed(cut)), 0, N, K, V)
+    ref = R.mix_matrix(lp, M.astype(np.float32).astype(np.float64))
+    assert maxerr(got, f32(ref)) < 2e-6
+    assert np.array_equal(got, stream(build(), 0, N, K, V))
