@@ -120,23 +120,21 @@ def main():
     from signals_amd import _native, runtime
     runtime.set_device(f'cuda:{local_rank}')
     _native.lib()
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-
-    from signals_amd.engine import BatchRenderer, KernelTimer
+    from signals_amd import parallel
+    from signals_amd.engine import KernelTimer
+    parallel.init_process_group()                        # RCCL (backend "nccl") when WORLD_SIZE > 1
     V, N, K = args.voices, args.frames, args.blocks
     params = synth_params(V * world)
     timer = None if args.no_kernel_timing else KernelTimer()
-    renderer = BatchRenderer(build_graph(params, rank * V, (rank + 1) * V), channels=2, rate=RATE, timer=timer)
+    renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
+                                        rate=RATE, timer=timer)
+    assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
 
     pos = args.position
 
     def step():
         nonlocal pos
-        bus = renderer.render(pos, N, K)                 # (K*N, 2) f32 on this GPU
-        if world > 1:
-            dist.all_reduce(bus)                         # RCCL sum of the stereo bus over xGMI
+        bus = renderer.render(pos, N, K)                 # (K*N, 2) f32: local render + RCCL all-reduce of the bus
         pos += N * K
         return bus
 

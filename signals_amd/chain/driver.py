@@ -88,7 +88,7 @@ class BlockDriver(Receiver):
         from signals_amd import chain, engine
         frames = self.blocksize if frames is None else frames
         if batched and self.input:
-            key = (chain.graph_version, self.input.sig, self._state.channels, self.rate)
+            key = (chain.graph_clock.version, self.input.sig, self._state.channels, self.rate)
             if self._engine_key != key:
                 self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate)
                 self._engine_key = key

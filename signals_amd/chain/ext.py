@@ -13,6 +13,7 @@ from signals_amd.chain import (
     BadStateValue,
     BlockCachingEmitter,
     ImplicitChannels,
+    PassThroughResult,
     Receiver,
     Request,
     as_control,
@@ -137,3 +138,20 @@ class MixMatrix(BlockCachingEmitter, Receiver):
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.to(torch.float32).contiguous()
         return _native.mix_matrix(x, self.resident_matrix(), torch.empty_like(x))
+
+
+class Tap(PassThroughResult):
+    """Stand-in for the reference's side-effect taps (vis.Wave / vis.Spec / files.FileWriter): forwards its
+    input unchanged, enabled or not; the original class name and state are kept for round-tripping."""
+
+    def __init__(self, cls_name: str = '', **state):
+        super().__init__()
+        self.original_cls_name = cls_name
+        self.original_state = state
+
+    @classmethod
+    def flags(cls) -> SignalFlags:
+        return super().flags() | SignalFlags.VIS
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        return self.input.forward(request)

@@ -34,16 +34,22 @@ class Scalar(Shaper, abc.ABC):
         return 1
 
 
-class Flatten(Scalar):
+class _FrameReduce(Scalar, abc.ABC):
+    """`Flatten` / `FlattenUnit` reduce over axis 0 -- the FRAME axis -- and answer a 1-D array, which
+    fails in the cache write with TypeError in the reference (shape.py:35, :41 ->
+    chain/__init__.py:446, :84).  Reproduced as is; use `ext.SumBus` for a voice sum."""
+    reduce = staticmethod(torch.sum)
 
     def _eval(self, request: Request) -> torch.Tensor:
-        return torch.sum(self.input.forward(request), dim=0)        # 1-D: TypeError downstream
+        return type(self).reduce(self.input.forward(request), dim=0)
 
 
-class FlattenUnit(Scalar):
+class Flatten(_FrameReduce):
+    reduce = staticmethod(torch.sum)
 
-    def _eval(self, request: Request) -> torch.Tensor:
-        return torch.mean(self.input.forward(request), dim=0)       # 1-D: TypeError downstream
+
+class FlattenUnit(_FrameReduce):
+    reduce = staticmethod(torch.mean)
 
 
 class Select(Scalar):

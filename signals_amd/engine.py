@@ -164,7 +164,7 @@ class _Batch:
         if self._need.get(key, -1) >= hist:
             return
         self._need[key] = hist
-        if not node.get_state().enabled:
+        if not node.get_state().enabled and not isinstance(node, ext.Tap):
             return
         if isinstance(node, fx.CritFilter):
             self._require(node.input.sig, channels, min(CONTEXT, self.pos))
@@ -175,7 +175,7 @@ class _Batch:
             self._require(node.left.sig, channels, hist)
         elif isinstance(node, ext.SumBus):
             self._require(node.input.sig, node.input.channels, hist)
-        elif isinstance(node, ext.MixMatrix):
+        elif isinstance(node, (ext.MixMatrix, ext.Tap)):
             self._require(node.input.sig, channels, hist)
         elif isinstance(node, shape.Merge):
             self._require(node.left.sig, node.left.channels, hist)
@@ -197,6 +197,9 @@ class _Batch:
         rows = hist + self.N * self.K
         dev = runtime.device()
         o = self.owner
+        if node is not None and isinstance(node, ext.Tap) and not node.get_state().enabled:
+            self._memo[key] = self._materialise(node.input.sig, channels)      # PASSTHRU: disabled = forward input
+            return self._memo[key]
         if node is None or not node.get_state().enabled:
             result = Emitter.empty_result()                       # (1,1) zeros broadcast everywhere
             self._memo[key] = (result, 0)
@@ -253,6 +256,10 @@ class _Batch:
             gains = node.resident_gains()
             result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=dev)
             o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+        elif isinstance(node, ext.Tap):
+            self._memo[key] = self._materialise(node.input.sig, channels)      # pass-through: same buffer
+            return self._memo[key]
 
         elif isinstance(node, ext.ADSR):
             ctl = node.control_rows(lambda bound: self._control(bound, bound.name))

@@ -1,0 +1,51 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/signals_amd.h declares;
+argument validation returns hipErrorInvalidValue without touching a device."""
+import ctypes
+import pathlib
+import re
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from signals_amd import _native
+    if not _native.LIB_PATH.exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(str(_native.LIB_PATH))
+
+
+def declared_symbols():
+    text = (ROOT / 'include' / 'signals_amd.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(sig_\w+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    from signals_amd import _native
+    assert declared_symbols() == sorted(_native.EXPORTS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_symbols():
+        assert getattr(lib, name) is not None, name
+    assert lib.sig_abi_version() == 1
+
+
+def test_argument_errors_do_not_reach_the_device(lib):
+    inv = 1     # hipErrorInvalidValue
+    lib.sig_osc_bank.restype = ctypes.c_int
+    lib.sig_osc_bank.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+    assert lib.sig_osc_bank(0, 0, 48000, 16, 4, None, 1, None, 1, None, 0, 4, None) == inv      # null pointers
+    assert lib.sig_osc_bank(0, -1, 48000, 16, 4, 8, 1, None, 1, 8, 0, 4, None) == inv           # negative position
+    assert lib.sig_osc_bank(0, 0, 48000, 16, 4, 8, 1, None, 1, 8, 0, 2, None) == inv            # ld < voices
+    assert lib.sig_osc_bank(0, 0, 48000, 0, 4, 8, 1, None, 1, 8, 0, 4, None) == 0               # empty: no launch
+    lib.sig_mix_matrix.restype = ctypes.c_int
+    lib.sig_mix_matrix.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    assert lib.sig_mix_matrix(32, 100, 16, 100, 16, 16, 100, None) == inv                        # voices % 64

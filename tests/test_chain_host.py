@@ -1,0 +1,256 @@
+"""Host-side node API on CPU (no kernels): shapes, block addresses, ports, state, cache, errors --
+the contract rows of SURVEY.md §8b, checked against the reference's documented behaviour
+(doctests at chain/__init__.py:26-51, :67-83) and the golden BlockLoc table."""
+import doctest
+import re
+
+import attr
+import numpy as np
+import pytest
+import torch
+
+import signals_amd
+import signals_amd.chain as chain
+from signals_amd import SignalFlags
+from signals_amd.chain import BadShape, BadStateSchema, BadStateValue, BlockLoc, Request, Shape, port
+from signals_amd.chain import ext, fixed, fx, noise, osc, shape
+
+
+@pytest.fixture(autouse=True)
+def _cpu_device():
+    from signals_amd import runtime
+    old = runtime._device
+    runtime.set_device('cpu')
+    yield
+    runtime._device = old
+
+
+class Probe(chain.Receiver):
+    input = port('input')
+
+    @classmethod
+    def flags(cls):
+        return SignalFlags(0)
+
+
+class Ramp(chain.BlockCachingEmitter, chain.ExplicitChannelsEmitter):
+    """test emitter: value = absolute frame index (+ channel/1000); counts evaluations"""
+
+    def __init__(self):
+        super().__init__()
+        self.evals = []
+
+    @classmethod
+    def flags(cls):
+        return SignalFlags.GENERATOR
+
+    def _eval(self, request: Request) -> torch.Tensor:
+        self.evals.append(request.loc)
+        n = torch.from_numpy(request.loc.frame_range.astype(np.float64))
+        return n + torch.arange(self.channels, dtype=torch.float64)[None, :] / 1000
+
+
+def loc(position, frames, channels, rate=48000):
+    return BlockLoc(position=position, rate=rate, shape=Shape(frames=frames, channels=channels))
+
+
+def test_doctests():
+    import signals_amd.chain.blocks as blocks
+    res = doctest.testmod(blocks)
+    assert res.failed == 0 and res.attempted >= 6
+
+
+def test_shape_semantics_match_reference_doctests():
+    s = Shape(frames=10, channels=2)
+    assert s == (10, 2) and s <= (10, 2) and s >= (10, 2) and not (s == (1, 1))
+    assert (1, 1) <= Shape(frames=10, channels=1) <= s
+    assert (1, 1) <= Shape(frames=1, channels=2) <= s
+    assert not ((0, 0) <= s) and not (Shape(frames=3, channels=2) <= s) and not (Shape(frames=10, channels=0) <= s)
+    assert Shape.of_array(np.array([[1, 2, 3]])) == (1, 3) and Shape.of_array(np.array([[1], [2], [2]])) == (3, 1)
+    with pytest.raises(TypeError):
+        Shape.of_array(np.array([]))
+    with pytest.raises(TypeError):
+        Shape.of_array(np.array([[[]]]))
+    assert Shape.unit() == (1, 1)
+
+
+def test_blockloc_integer_rows_bit_exact(golden):
+    for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
+        l = loc(int(pos), int(n), 4)
+        b, a = l.before(100), l.after(100)
+        assert (b.position, b.shape.frames, a.position, a.shape.frames) == (bp, bf, ap, af)
+        fr = l.frame_range
+        assert fr.dtype == np.int64 and fr.shape == (n, 1) and fr[0, 0] == fr0 and fr[-1, 0] == fr1
+        assert not fr.flags.writeable
+        assert (int(b <= l), int(l <= l), int(l.resize(1) <= l)) == (b_le, l_le, r_le)
+    l = loc(512, 256, 4)
+    assert l.end_position == 768 and l.timestamp == 512 / 48000
+    assert l.resize(256) is l and l.reslice(4) is l and l.reslice(2).shape == (256, 2)
+    assert hash(l) == hash(loc(512, 256, 4)) and l != loc(512, 256, 4, rate=44100)
+    assert not (loc(512, 256, 4) <= loc(512, 256, 4, rate=44100))
+    with pytest.raises(attr.exceptions.FrozenInstanceError):
+        l.position = 3
+
+
+def test_ports_connect_disconnect_and_names():
+    assert osc.Sine.port_names() == ['hertz', 'phase']
+    assert fx.Mix.port_names() == ['left', 'mix', 'right']
+    assert fx.Gain.port_names() == fx.RingMod.port_names() == fx.Amp.port_names() == ['left', 'right']
+    assert fx.LowPass.port_names() == fx.HighPass.port_names() == ['cutoff', 'input']
+    assert fx.BandPass.port_names() == fx.BandStop.port_names() == ['high', 'input', 'low']
+    assert shape.Merge.port_names() == ['left', 'right'] and shape.Flatten.port_names() == ['input']
+    s, f = osc.Sine(), fixed.Fixed()
+    assert not s.hertz and s.hertz.channels is None
+    s.hertz = f
+    assert s.hertz and s.hertz.sig is f and ('hertz', s) in f.outputs_with_ports and s.inputs_by_port == {'hertz': f}
+    g = fixed.Fixed()
+    s.hertz = g                       # re-assign expels the old emitter
+    assert not f.outputs_with_ports and ('hertz', s) in g.outputs_with_ports
+    del s.hertz
+    assert not s.hertz and not g.outputs_with_ports
+    p = Probe(); p.input = s
+    s.destroy()                       # emitter.destroy unplugs every consumer
+    assert not p.input
+
+
+def test_qualified_names_and_flags():
+    assert osc.Sine.cls_name() == 'signals.chain.osc.Sine' and fx.LowPass.cls_name() == 'signals.chain.fx.LowPass'
+    assert fixed.Fixed.cls_name() == 'signals.chain.fixed.Fixed' and noise.White.cls_name() == 'signals.chain.noise.White'
+    assert osc.Sine.flags() == SignalFlags.GENERATOR and fx.Gain.flags() == SignalFlags.EFFECT
+    assert SignalFlags.AUDIO == SignalFlags.GENERATOR | SignalFlags.EFFECT | SignalFlags.SOURCE_DEVICE
+    from signals_amd.chain.driver import load_signal
+    assert load_signal('signals.chain.osc.Triangle') is osc.Triangle
+    assert load_signal('signals_amd.chain.ext.SumBus') is ext.SumBus
+    with pytest.raises(TypeError):
+        load_signal('signals.chain.osc.Osc')        # abstract
+    signals_amd.install_as_signals()
+    import signals.chain.fx
+    assert signals.chain.fx.Gain is fx.Gain
+
+
+def test_state_schema_and_validation():
+    f = fixed.Fixed()
+    assert f.state_attrs() == {'enabled', 'value'} and f.get_state().value.shape == (1, 1)
+    f.get_state().value = np.array([[330]])
+    assert f.channels == 1
+    with pytest.raises(BadStateValue):
+        f.get_state().value = np.array([1.0, 2.0])
+    with pytest.raises(BadStateValue):
+        f.get_state().value = [[1.0]]
+    with pytest.raises(BadStateSchema):
+        f.set_state(osc.Sine.State())
+    with pytest.raises(TypeError):
+        fixed.Fixed.State(enabled='yes')
+    w = noise.White()
+    assert w.state_attrs() == {'enabled', 'channels', 'seed'} and w.channels == 1
+    with pytest.raises(ValueError):
+        noise.White.State(channels=0)
+    assert str(BadShape(f, (3, 2), (10, 2))).startswith("BadShape Invalid response from 'signals.chain.fixed.Fixed'")
+
+
+def test_fixed_resident_copy_tracks_the_array():
+    f = fixed.Fixed()
+    v = np.array([[220]])                     # int64, like a .sigs value
+    f.get_state().value = v
+    t = f.resident()
+    assert t.dtype == torch.float64 and t.shape == (1, 1) and t[0, 0] == 220.0
+    assert f.resident() is t                  # no re-upload
+    v[0, 0] = 440                             # in-place edit is seen, like the reference's shared array
+    assert f.resident()[0, 0] == 440.0
+    f.get_state().value = np.ones((5, 2))
+    assert f.resident().dtype == torch.float32 and f.resident().shape == (5, 2)
+
+
+def test_unplugged_and_disabled_answer_unit_zero():
+    p = Probe()
+    z = p.input.request(loc(0, 256, 2))
+    assert z.shape == (1, 1) and z.dtype == torch.float64 and z[0, 0] == 0
+    r = Ramp(); r.get_state().channels = 2; r.get_state().enabled = False
+    p.input = r
+    assert p.input.request(loc(0, 256, 2)).shape == (1, 1) and r.evals == []
+
+
+def test_bad_shape_is_raised_at_the_port():
+    r = Ramp(); r.get_state().channels = 3
+    p = Probe(); p.input = r
+    with pytest.raises(BadShape):
+        p.input.request(loc(0, 16, 2))
+    assert p.input.request(loc(0, 16, 3)).shape == (16, 3)
+
+
+def test_block_cache_exact_hit_containment_slice_and_fifo():
+    r = Ramp(); r.get_state().channels = 2
+    p = Probe(); p.input = r
+    a = p.input.request(loc(0, 256, 2))
+    assert p.input.request(loc(0, 256, 2)) is a and len(r.evals) == 1          # exact hit: same object
+    s = p.input.request(loc(100, 50, 1))                                        # contained: sliced view
+    assert len(r.evals) == 1 and s.shape == (50, 1) and s.data_ptr() == a[100:150, :1].data_ptr()
+    assert s[0, 0] == 100.0
+    p.input.request(loc(200, 100, 2))                                           # overlaps the end: miss
+    assert len(r.evals) == 2
+    for k in range(1, 17):                                                      # 16 more -> first key evicted
+        p.input.request(loc(1000 * k, 8, 2))
+    assert len(r._block_cache) == 16 and loc(0, 256, 2) not in r._block_cache
+    p.input.request(loc(0, 256, 2))
+    assert len(r.evals) == 19
+    assert not (loc(0, 256, 2) <= loc(0, 256, 2, rate=44100))
+
+
+def test_forward_with_context_request_pattern():
+    """before / block / after, clamped at 0, like chain/__init__.py:308-315 + :149-159"""
+    r = Ramp(); r.get_state().channels = 1
+    p = Probe(); p.input = r
+    w = p.input.forward_with_context(Request(requestor=p, port='input', loc=loc(0, 64, 1)), 100)
+    assert [(l.position, l.shape.frames) for l in r.evals] == [(0, 64), (64, 100)] and w.shape == (164, 1)
+    r2 = Ramp(); r2.get_state().channels = 1
+    p.input = r2
+    w = p.input.forward_with_context(Request(requestor=p, port='input', loc=loc(30, 64, 1)), 100)
+    assert [(l.position, l.shape.frames) for l in r2.evals] == [(0, 30), (30, 64), (94, 100)]
+    assert torch.equal(w[:, 0], torch.arange(0, 194, dtype=torch.float64))
+    ctl = p.input.forward_at_block_rate(Request(requestor=p, port='input', loc=loc(500, 64, 1)))
+    assert ctl.shape == (1, 1) and ctl[0, 0] == 500.0
+
+
+def test_upstream_order_and_cycle_detection():
+    o = osc.Sine(); g = fx.Gain(); lp = fx.LowPass(); m = shape.Merge()
+    g.left = o; lp.input = g; m.left = lp; m.right = g
+    up = list(m.upstream())
+    assert up[-1] is m and up.index(o) < up.index(g) < up.index(lp)
+    a, b = fx.Gain(), fx.Gain()
+    a.left = b; b.left = a
+    with pytest.raises(AssertionError, match='Cycle'):
+        a.upstream()
+
+
+def test_implicit_channels():
+    g = fx.Gain()
+    a = fixed.Fixed(); a.get_state().value = np.zeros((1, 8))
+    b = fixed.Fixed()
+    g.left = a; g.right = b
+    assert g.channels == 8                                  # the one non-1 width
+    c = fixed.Fixed(); c.get_state().value = np.zeros((1, 4))
+    g.right = c
+    with pytest.raises(ValueError):
+        g.channels
+    m = shape.Merge(); m.left = a; m.right = c
+    assert m.channels == 12
+
+
+def test_kernels_refuse_cpu_tensors_loudly():
+    from signals_amd._native import NativeError
+    s = osc.Sine()
+    f = fixed.Fixed(); f.get_state().value = np.array([[440.0]])
+    s.hertz = f
+    p = Probe(); p.input = s
+    with pytest.raises(NativeError, match='no CPU fallback'):
+        p.input.request(loc(0, 64, 1))
+
+
+def test_graph_version_bumps_on_mutation():
+    v0 = chain.graph_clock.version
+    s = osc.Sine(); f = fixed.Fixed()
+    s.hertz = f
+    assert chain.graph_clock.version > v0
+    v1 = chain.graph_clock.version
+    s.set_state(osc.Sine.State(enabled=False))
+    assert chain.graph_clock.version > v1
