@@ -34,7 +34,8 @@ RATE = 48000
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 # algorithmic HBM bytes per voice-sample, f32 storage, every node output written once and read once
 # per consumer (SURVEY.md §8d, C2 = 24 B over the four kernels)
-ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4}
+ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
+              'fused_osc_biquad': 4}      # fused chain: only the f32 store reaches HBM
 
 
 def synth_params(total_voices: int):
@@ -109,6 +110,8 @@ def main():
     ap.add_argument('--position', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--materialised', action='store_true', help='headline = one kernel per node (no fusion)')
+    ap.add_argument('--single-mode', action='store_true', help='skip the second (alternative schedule) measurement')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -125,18 +128,6 @@ def main():
     parallel.init_process_group()                        # RCCL (backend "nccl") when WORLD_SIZE > 1
     V, N, K = args.voices, args.frames, args.blocks
     params = synth_params(V * world)
-    timer = None if args.no_kernel_timing else KernelTimer()
-    renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
-                                        rate=RATE, timer=timer)
-    assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
-
-    pos = args.position
-
-    def step():
-        nonlocal pos
-        bus = renderer.render(pos, N, K)                 # (K*N, 2) f32: local render + RCCL all-reduce of the bus
-        pos += N * K
-        return bus
 
     def fence():
         torch.cuda.synchronize()
@@ -144,61 +135,95 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if timer:
-        timer.reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        bus = step()
-    fence()
-    dt = time.perf_counter() - t0
-    runtime.check_status()
-    assert torch.isfinite(bus).all()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        samples = V * world * N * K * args.steps
-        line = {
-            'metric': 'rendered Msamples/s (48 kHz, 256-sample blocks)',
-            'value': samples / dt / 1e6,
-            'unit': 'Msamples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'C2: {V}-voice Fixed->Sine->LowPass->Gain->SumBus(stereo) per GPU, 48 kHz, '
-                                   f'{N}-frame blocks, {K} blocks per batch, node-materialised engine (f32 storage, '
-                                   f'f64 phase/recurrence)',
-                       'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
-                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL all-reduce of the stereo bus'},
-        }
+    def measure(fuse: bool, steps: int, warmup: int) -> dict:
+        """W untimed + exactly `steps` timed batches of this rank's 1024-voice graph (+ bus all-reduce)"""
+        timer = None if args.no_kernel_timing else KernelTimer()
+        renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
+                                            rate=RATE, timer=timer, fuse=fuse)
+        assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
+        pos = args.position
+        for _ in range(warmup):
+            renderer.render(pos, N, K)
+            pos += N * K
+        fence()
+        if timer:
+            timer.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bus = renderer.render(pos, N, K)             # (K*N, 2) f32: local render + RCCL all-reduce of the bus
+            pos += N * K
+        fence()
+        dt = time.perf_counter() - t0
+        runtime.check_status()
+        assert torch.isfinite(bus).all()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        samples = V * world * N * K * steps
+        res = {'value': samples / dt / 1e6, 'ms_per_step': dt / steps * 1e3}
         if timer:
             summ = timer.summary()
             total_ms = sum(e['ms'] for e in summ.values())
             kernels = {}
             for name, e in summ.items():
-                fam = name.split('[')[0]
-                bpu = ALGO_BYTES.get(fam, 0)
+                bpu = ALGO_BYTES.get(name.split('[')[0], 0)
                 avg_ms = e['ms'] / e['calls']
                 kernels[name] = {'calls': e['calls'], 'avg_ms': avg_ms, 'share': e['ms'] / total_ms,
+                                 'algo_bytes_per_voice_sample': bpu,
                                  'algo_GBs': bpu * (e['units'] / e['calls']) / (avg_ms * 1e-3) / 1e9}
             dom = max(summ, key=lambda k: summ[k]['ms'])
             traffic = None
             tfile = ROOT / 'profiles' / 'traffic.json'
             if tfile.exists():
                 traffic = json.loads(tfile.read_text()).get(dom.split('[')[0])
-            line['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['algo_GBs'],
-                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['algo_GBs'] / HBM_PEAK_GBS,
-                                'traffic': traffic,
-                                'algo_bytes_per_voice_sample': ALGO_BYTES.get(dom.split('[')[0]),
-                                'avg_launch_ms': kernels[dom]['avg_ms']}
-            line['kernels'] = kernels
-            line['pipeline_algo_GBs'] = 24 * samples / world / dt / 1e9
+            res['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['algo_GBs'],
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['algo_GBs'] / HBM_PEAK_GBS,
+                               'traffic': traffic,
+                               'algo_bytes_per_voice_sample': kernels[dom]['algo_bytes_per_voice_sample'],
+                               'avg_launch_ms': kernels[dom]['avg_ms']}
+            if dom.startswith('fused_osc_biquad'):
+                # f64-VALU-bound kernel: 25 f64-rate instructions per (voice, row) update (12 phase + 3 cvt + 8
+                # recurrence + gain + compare, counted in the ISA; DESIGN.md §4), (N+c)/N updates per stored
+                # sample; peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz
+                upd = (summ[dom]['units'] / summ[dom]['calls']) * (N + 100) / N
+                ach = 25 * upd / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
+                res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
+                                               'frac': ach / 39.3}
+            res['kernels'] = kernels
+        return res
+
+    main_mode = measure(fuse=not args.materialised, steps=args.steps, warmup=args.warmup)
+    other = None
+    if not args.single_mode:
+        other = measure(fuse=args.materialised, steps=max(3, args.steps // 2), warmup=min(2, args.warmup))
+
+    if rank == 0:
+        def describe(fused):
+            return ('fused voice chain: sig_fused_osc_biquad (Sine->LowPass->Gain in one launch, oscillator and filter '
+                    'outputs never stored) + sig_sum_bus' if fused else
+                    'node-materialised: one kernel per node (osc_bank, biquad_coldstart, elementwise[Gain], sum_bus), '
+                    'every edge f32 in HBM (24 B/voice-sample, SURVEY.md 8d)')
+        line = {
+            'metric': 'rendered Msamples/s (48 kHz, 256-sample blocks)',
+            'value': main_mode['value'],
+            'unit': 'Msamples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': main_mode['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'C2: {V}-voice Fixed->Sine->LowPass->Gain->SumBus(stereo) per GPU, 48 kHz, '
+                                   f'{N}-frame blocks, {K} blocks per batch (f32 storage, f64 phase/recurrence); '
+                                   f'engine schedule = {describe(not args.materialised)}',
+                       'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
+                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL all-reduce of the stereo bus'},
+        }
+        for k in ('roofline', 'kernels'):
+            if k in main_mode:
+                line[k] = main_mode[k]
+        if other is not None:
+            other['schedule'] = describe(args.materialised)
+            line['alt_schedule'] = other
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(params, V, N)
         print(json.dumps(line), flush=True)

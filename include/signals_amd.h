@@ -123,6 +123,18 @@ int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices,
 int sig_mix_matrix(int64_t rows, int32_t voices, const float* x, int64_t x_ld,
                    const float* matrix, float* out, int64_t out_ld, void* stream);
 
+/* Fused voice chain, chosen by the batched engine when the intermediate node outputs have no other
+ * consumer:  out = [gain *] Filter(Osc)  for `nblocks` cold-started blocks, i.e. sig_osc_bank ->
+ * sig_biquad_coldstart -> sig_elementwise(GAIN) without the oscillator / filter stores
+ * (osc.py:26-62 + fx.py:85-121 + fx.py:51-52).  Context rows are recomputed from the position-pure
+ * oscillator.  f32 store; gain == NULL skips the gain stage; cutoff is one (1,V)|(1,1) row. */
+int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                         const double* cutoff, int32_t cutoff_stride,
+                         const double* gain, int32_t gain_stride,
+                         float* out, int64_t out_ld, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

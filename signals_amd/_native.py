@@ -19,7 +19,7 @@ EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
-           'sig_white_noise', 'sig_adsr', 'sig_mix_matrix')
+           'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad')
 
 
 class NativeError(RuntimeError):
@@ -61,6 +61,9 @@ def lib() -> ctypes.CDLL:
                                vp, i32, i64, vp]
         L.sig_mix_matrix.restype = ctypes.c_int
         L.sig_mix_matrix.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp]
+        L.sig_fused_osc_biquad.restype = ctypes.c_int
+        L.sig_fused_osc_biquad.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                           dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
         if L.sig_abi_version() != 1:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -226,4 +229,25 @@ def mix_matrix(x: torch.Tensor, matrix: torch.Tensor, out: torch.Tensor) -> torc
         raise NativeError(f'mix_matrix shapes: x {tuple(x.shape)} matrix {tuple(matrix.shape)} out {tuple(out.shape)}')
     _check(lib().sig_mix_matrix(x.shape[0], x.shape[1], x.data_ptr(), x.stride(0), matrix.data_ptr(),
                                 out.data_ptr(), out.stride(0), _stream(out)), 'sig_mix_matrix')
+    return out
+
+
+def fused_osc_biquad(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                     hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
+                     gain: torch.Tensor | None, out: torch.Tensor, status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (nblocks*block_frames, voices) f32 <- [gain *] Filter(Osc), every block cold-started"""
+    _gpu(hertz, phase, cutoff, gain, out, status)
+    _audio(out, 'fused out')
+    rows, voices = out.shape
+    if out.dtype != torch.float32 or rows != block_frames * nblocks:
+        raise NativeError(f'fused out must be float32 ({block_frames * nblocks}, V), got {tuple(out.shape)} {out.dtype}')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    _check(lib().sig_fused_osc_biquad(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
+                                      voices, *ptrs, out.data_ptr(), out.stride(0),
+                                      status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_fused_osc_biquad')
     return out

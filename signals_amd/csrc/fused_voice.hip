@@ -1,0 +1,156 @@
+// Fused voice chain for gfx950: Osc -> cold-start Butterworth biquad -> [x per-voice gain] -> f32 store,
+// K blocks per launch.  Chosen by the batched engine when a LowPass/HighPass reads an oscillator nobody
+// else consumes (and, optionally, feeds a Gain nobody else consumes): the oscillator samples never touch
+// HBM, so the stage costs 4 B/voice-sample (the store) instead of 4 + 8 (+ 8).
+//
+// Same arithmetic as the node kernels (sig_osc.h, sig_biquad.h; reference osc.py:26-62, fx.py:85-121,
+// fx.py:51-52): f64 phase, f64 recurrence from zero state over [c context rows | block], context rows are
+// recomputed (the oscillator is position-pure), the filter input is the oscillator's f64 sample rather
+// than its f32-rounded store, and the gain multiplies the f64 filter output before the single f32
+// rounding -- i.e. strictly closer to the f64 reference than the materialised path.
+//
+// Mapping: one wave = 64*VPT consecutive voices of ONE block, lanes walk c+N rows serially; the per-row
+// quotient n/rate (IEEE f64 divide) is computed 64 rows at a time, one row per lane, and broadcast with
+// v_readlane.  f64-VALU-bound: ~(15 osc + 9 filter + 2) x (N+c)/N f64-rate ops per voice-sample.
+#include <cstdlib>
+
+#include "sig_biquad.h"
+#include "sig_osc.h"
+
+namespace {
+
+using sig_biquad::Biquad;
+using sig_biquad::design_butter2;
+
+template <int VPT> struct OutVec;
+template <> struct OutVec<1> { using type = float; };
+template <> struct OutVec<2> { using type = float2; };
+template <> struct OutVec<4> { using type = float4; };
+
+__device__ __forceinline__ void put(float& v, const float (&y)[1]) { v = y[0]; }
+__device__ __forceinline__ void put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
+__device__ __forceinline__ void put(float4& v, const float (&y)[4]) { v = make_float4(y[0], y[1], y[2], y[3]); }
+
+struct FusedArgs {
+    int type; double rate; int64_t position; int N, K, ctx, voices;
+    const double* hertz; int hs; const double* phase; int ps;
+    const double* cutoff; int cs; const double* gain; int gs;
+    float* out; int64_t out_ld; int voice_tiles; int* status;
+};
+
+template <int KIND, int VPT, bool GAIN>
+__global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
+{
+    using Vec = typename OutVec<VPT>::type;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int vt = (int)(item % a.voice_tiles);
+    const int64_t b = item / a.voice_tiles;
+    if (b >= a.K) return;                                                     // wave-uniform
+    const int v0 = (vt * SIG_WAVE + lane) * VPT;
+    const bool live = v0 < a.voices;
+    const int vc = live ? v0 : 0;
+
+    const int64_t p_b = a.position + b * a.N;
+    const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+    const int64_t n0 = p_b - c;                                               // absolute frame of row 0
+    const int total = c + a.N;
+
+    Biquad q[VPT];
+    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], g[VPT];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = (vc + i < a.voices) ? vc + i : vc;
+        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q[i]);
+        hz[i] = a.hertz[(int64_t)v * a.hs];
+        ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+        g[i] = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
+        z0[i] = 0.0; z1[i] = 0.0;
+    }
+    if (!ok && live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+
+    float* dst = a.out + (b * a.N - c) * a.out_ld + vc;                      // rows < c are never stored
+    for (int r0 = 0; r0 < total; r0 += SIG_WAVE) {
+        const double q_lane = (double)(n0 + r0 + lane) / a.rate;             // osc.py:32, one row per lane
+        const int lim = (total - r0 < SIG_WAVE) ? total - r0 : SIG_WAVE;
+        for (int j = 0; j < lim; ++j) {
+            const double t_s = sig_readlane_f64(q_lane, j);
+            const int r = r0 + j;
+            float y32[VPT];
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const double t = t_s * hz[i] + ph[i];
+                const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                        : sig_osc::osc_wave<KIND, double>(t);
+                const double y = q[i].b0 * x + z0[i];                         // scipy _sosfilt order, contract off
+                z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
+                z1[i] = q[i].b2 * x - q[i].a2 * y;
+                y32[i] = (float)(GAIN ? y * g[i] : y);
+            }
+            if (r >= c && live) {
+                Vec o; put(o, y32);
+                *reinterpret_cast<Vec*>(dst + (int64_t)r * a.out_ld) = o;
+            }
+        }
+    }
+}
+
+int fused_variant() {
+    static int v = [] { const char* e = getenv("SIG_FUSED_VPT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+template <int KIND, bool GAIN>
+int launch_fused(FusedArgs a, hipStream_t stream)
+{
+    auto ok = [&](int vpt) {
+        return (a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0);
+    };
+    int vpt = fused_variant() ? fused_variant() : 2;
+    if (!ok(vpt)) vpt = 1;
+    const int span = SIG_WAVE * vpt;
+    a.voice_tiles = (a.voices + span - 1) / span;
+    const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    switch (vpt) {
+        case 1: fused_osc_biquad_kernel<KIND, 1, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
+        case 2: fused_osc_biquad_kernel<KIND, 2, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
+        case 4: fused_osc_biquad_kernel<KIND, 4, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return sig_launch_status();
+}
+
+template <bool GAIN>
+int dispatch_kind(int kind, const FusedArgs& a, hipStream_t s)
+{
+    switch (kind) {
+        case SIG_OSC_SINE: return launch_fused<SIG_OSC_SINE, GAIN>(a, s);
+        case SIG_OSC_SQUARE: return launch_fused<SIG_OSC_SQUARE, GAIN>(a, s);
+        case SIG_OSC_SAWTOOTH: return launch_fused<SIG_OSC_SAWTOOTH, GAIN>(a, s);
+        case SIG_OSC_TRIANGLE: return launch_fused<SIG_OSC_TRIANGLE, GAIN>(a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace
+
+extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                    int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                    const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                    const double* cutoff, int32_t cutoff_stride,
+                                    const double* gain, int32_t gain_stride,
+                                    float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                out, out_ld, 0, status};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
+}

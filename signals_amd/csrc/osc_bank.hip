@@ -8,92 +8,11 @@
 // v_readlane, so the per-sample cost is mul + add + waveform.
 //
 // Roofline: 4 B written per voice-sample (f32), no reads beyond 2 x 8 B per voice per wave.
-#include "sig_common.h"
+#include "sig_osc.h"
 
 namespace {
 
-constexpr double kPi = 3.141592653589793115997963468544185161590576171875;   // np.pi
-constexpr double kPiTail = 1.2246467991473532e-16;                            // pi - fl(pi)
-constexpr double kTwoPiHi = 6.28318530717958623199592693708837032318115234375;
-constexpr double kTwoPiLo = 2.4492935982947064e-16;
-
-// sin(x) for |x| <= pi/2 + eps, odd Taylor polynomial through x^21 (remainder < 2e-18).
-__device__ __forceinline__ double sin_poly(double x) {
-    const double s = x * x;
-    double p = -1.9572941063391263e-20;                 // -1/21!
-    p = fma(p, s, 8.2206352466243295e-18);              //  1/19!
-    p = fma(p, s, -2.8114572543455206e-15);             // -1/17!
-    p = fma(p, s, 7.6471637318198164e-13);              //  1/15!
-    p = fma(p, s, -1.6059043836821613e-10);             // -1/13!
-    p = fma(p, s, 2.5052108385441720e-08);              //  1/11!
-    p = fma(p, s, -2.7557319223985893e-06);             // -1/9!
-    p = fma(p, s, 1.9841269841269841e-04);              //  1/7!
-    p = fma(p, s, -8.3333333333333332e-03);             // -1/5!
-    p = fma(p, s, 1.6666666666666666e-01);              //  1/3!   (sign folded below)
-    // sin x = x - x^3/6 + ... ; the chain above carries alternating signs starting at +1/3!
-    return fma(-(x * s), p, x);
-}
-
-// np.sin(t * 2 * np.pi) reproduced including the reference's own argument rounding:
-//   a = fl(fl(2t) * fl(pi)) is what numpy hands to libm.  a = 2*pi*t + delta with
-//   delta = -(fl(2t)*fl(pi) - a) - 2t*(pi - fl(pi)); the first term is exact via fma.
-// So sin(a) = sin(2*pi*frac(t) + delta), evaluated with frac(t) exact in f64.
-__device__ __forceinline__ double osc_sine(double t) {
-    const double t2 = t * 2.0;
-    const double a = t2 * kPi;
-    const double e = fma(t2, kPi, -a);
-    const double delta = -e - t2 * kPiTail;
-    const double r = t - rint(t);                       // exact, |r| <= 0.5
-    const double k = rint(r + r);                       // -1, 0, +1: half-turns to remove
-    const double rq = fma(k, -0.5, r);                  // exact, |rq| <= 0.25
-    const double x = fma(rq, kTwoPiHi, fma(rq, kTwoPiLo, delta));
-    const double y = sin_poly(x);
-    // sin(theta + pi*k) = -sin(theta) for odd k: flip the sign bit, branch-free
-    const int flip = (k != 0.0) ? (int)0x80000000 : 0;
-    return __hiloint2double(__double2hiint(y) ^ flip, __double2loint(y));
-    // domain: |t| < 2^51 cycles (beyond that f64 has no fraction bits left)
-}
-
-__device__ __forceinline__ double osc_square(double t) {       // osc.py:48-49
-    return sig_sign(0.5 - sig_npmod_pow2<1>(t));
-}
-
-__device__ __forceinline__ double osc_sawtooth(double t) {     // osc.py:54-55
-    return 2.0 * sig_npmod_pow2<1>(t - 0.5) - 1.0;
-}
-
-__device__ __forceinline__ double osc_triangle(double t) {     // osc.py:60-62
-    const double u = t - 0.25;
-    return (4.0 * sig_npmod_pow2<2>(u) - 1.0) * sig_sign(sig_npmod_pow2<1>(u) - 0.5);
-}
-
-// f32 store path of Sine: same exact phase reduction, then the hardware sine (v_sin_f32 takes
-// REVOLUTIONS; measured max |err| 1.07e-7 on [-0.25, 0.25]).  Total error vs the reference
-// <= 1.3e-7 (bar 1e-6), at 15 f64-rate ops per sample instead of 27, which is what makes the kernel
-// HBM-write-bound instead of f64-VALU-bound.
-constexpr double kInvTwoPi = 0.15915494309189535;
-__device__ __forceinline__ float osc_sine_f32(double t) {
-    const double t2 = t + t;
-    const double a = t2 * kPi;
-    const double e = fma(t2, kPi, -a);                  // a + e == t2 * fl(pi) exactly
-    const double s = fma(t2, kPiTail, e);               // -(delta): how far numpy's argument is from 2*pi*t
-    const double r = t - rint(t);
-    const double k = rint(r + r);
-    const double rq = fma(k, -0.5, r);                  // exact, |rq| <= 0.25
-    const float rev = (float)fma(s, -kInvTwoPi, rq);
-    const float y = __builtin_amdgcn_sinf(rev);
-    return __uint_as_float(__float_as_uint(y) ^ ((k != 0.0) ? 0x80000000u : 0u));
-}
-
-template <int KIND, typename OUT> __device__ __forceinline__ OUT osc_wave(double t) {
-    if (KIND == SIG_OSC_SINE) {
-        if (sizeof(OUT) == 4) return (OUT)osc_sine_f32(t);
-        return (OUT)osc_sine(t);
-    }
-    if (KIND == SIG_OSC_SQUARE) return (OUT)osc_square(t);
-    if (KIND == SIG_OSC_SAWTOOTH) return (OUT)osc_sawtooth(t);
-    return (OUT)osc_triangle(t);
-}
+using sig_osc::osc_wave;
 
 constexpr int kRowsPerWave = 16;
 constexpr int kWavesPerWg = 4;

@@ -81,10 +81,102 @@ __global__ __launch_bounds__(256) void sum_bus_kernel(int64_t rows, int voices, 
     }
 }
 
+// Fast path (f32 in, voices == 256*CHUNKS <= 1024, 16-B aligned rows): the lane's gains for all of its
+// voices stay in VGPRs (C*4*CHUNKS doubles), each wave strides over row groups of kFastRows rows, and all
+// CHUNKS*kFastRows 16-B loads of a group are issued before the first FMA.  The summation order per
+// (row, channel) is the same as the generic kernel's: chunk-major within the lane, then the butterfly.
+constexpr int kFastRows = 4;
+
+template <int C, bool GAINS, int CHUNKS>
+__global__ __launch_bounds__(256) void sum_bus_fast_kernel(int64_t rows, const float* __restrict__ x, int64_t ld,
+                                                           const double* __restrict__ gains, int64_t gld,
+                                                           void* __restrict__ out, int64_t out_ld, int out_f64)
+{
+    const int lane = threadIdx.x & 63;
+    double g[CHUNKS][C][4];
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[j][c][i] = GAINS ? gains[c * gld + 256 * j + 4 * lane + i] : 1.0;
+
+    const int64_t groups = (rows + kFastRows - 1) / kFastRows;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = grp * kFastRows;
+        float4 xv[kFastRows][CHUNKS];
+#pragma unroll
+        for (int r = 0; r < kFastRows; ++r) {
+            const int64_t row = (r0 + r < rows) ? r0 + r : rows - 1;
+#pragma unroll
+            for (int j = 0; j < CHUNKS; ++j)
+                xv[r][j] = *reinterpret_cast<const float4*>(x + row * ld + 256 * j + 4 * lane);
+        }
+        double acc[kFastRows][C];
+#pragma unroll
+        for (int r = 0; r < kFastRows; ++r) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[r][c] = 0.0;
+#pragma unroll
+            for (int j = 0; j < CHUNKS; ++j) {
+                const double e[4] = {(double)xv[r][j].x, (double)xv[r][j].y, (double)xv[r][j].z, (double)xv[r][j].w};
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[r][c] = GAINS ? fma(g[j][c][i], e[i], acc[r][c]) : acc[r][c] + e[i];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kFastRows; ++r)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                double s = acc[r][c];
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) s += sig_shfl_xor_f64(s, m);
+                acc[r][c] = s;
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < kFastRows; ++r) {
+                if (r0 + r >= rows) break;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (out_f64) ((double*)out)[(r0 + r) * out_ld + c] = acc[r][c];
+                    else ((float*)out)[(r0 + r) * out_ld + c] = (float)acc[r][c];
+                }
+            }
+        }
+    }
+}
+
+template <int C, bool GAINS>
+bool launch_bus_fast(int64_t rows, int voices, const float* x, int64_t ld, const double* gains, int64_t gld,
+                     void* out, int64_t out_ld, int out_f64, hipStream_t stream)
+{
+    if (voices % 256 || voices > 1024 || ld % 4 || reinterpret_cast<uintptr_t>(x) % 16) return false;
+    const int64_t groups = (rows + kFastRows - 1) / kFastRows;
+    int64_t nwg = (groups + 3) / 4;
+    if (nwg > 256 * 8) nwg = 256 * 8;
+    switch (voices / 256) {
+        case 1: sum_bus_fast_kernel<C, GAINS, 1><<<(unsigned)nwg, 256, 0, stream>>>(rows, x, ld, gains, gld, out, out_ld, out_f64); break;
+        case 2: sum_bus_fast_kernel<C, GAINS, 2><<<(unsigned)nwg, 256, 0, stream>>>(rows, x, ld, gains, gld, out, out_ld, out_f64); break;
+        case 3: sum_bus_fast_kernel<C, GAINS, 3><<<(unsigned)nwg, 256, 0, stream>>>(rows, x, ld, gains, gld, out, out_ld, out_f64); break;
+        case 4: sum_bus_fast_kernel<C, GAINS, 4><<<(unsigned)nwg, 256, 0, stream>>>(rows, x, ld, gains, gld, out, out_ld, out_f64); break;
+    }
+    return true;
+}
+
 template <typename T, int C>
 int launch_bus(int64_t rows, int voices, const T* x, int64_t ld, const double* gains, int64_t gld,
                void* out, int64_t out_ld, int out_f64, hipStream_t stream)
 {
+    if (sizeof(T) == 4 && C <= 2) {
+        const float* xf = reinterpret_cast<const float*>(x);
+        const bool done = gains ? launch_bus_fast<C, true>(rows, voices, xf, ld, gains, gld, out, out_ld, out_f64, stream)
+                                : launch_bus_fast<C, false>(rows, voices, xf, ld, gains, gld, out, out_ld, out_f64, stream);
+        if (done) return sig_launch_status();
+    }
     const bool vec4 = (voices % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % (4 * sizeof(T)) == 0);
     const int64_t nwg = (rows + 4 * kRows - 1) / (4 * kRows);
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;

@@ -74,7 +74,11 @@ class KernelTimer:
 
 class BatchRenderer:
 
-    def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None):
+    def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
+                 fuse: bool = True):
+        """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
+        no other consumer (sig_fused_osc_biquad).  Off = one kernel per node, bit-identical to the eager path."""
+        self.fuse = fuse
         self.node = node
         self.channels = channels
         self.rate = rate
@@ -205,7 +209,11 @@ class _Batch:
             self._memo[key] = (result, 0)
             return self._memo[key]
 
-        if isinstance(node, fixed.Fixed):
+        fused = self._try_fuse(node, channels, hist) if o.fuse else None
+        if fused is not None:
+            result = fused
+
+        elif isinstance(node, fixed.Fixed):
             value = node.resident()
             if value.shape[0] != 1:
                 raise NotBatchable('multi-row Fixed as an audio source')
@@ -299,6 +307,43 @@ class _Batch:
         if full.shape[0] == 1:
             return full
         return full[have - hist:] if have != hist else full
+
+    # -------------------------------------------------------------- fusion
+    def _try_fuse(self, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
+        """[Gain(] LowPass|HighPass(Osc) [)] -> one launch, when nothing else reads the intermediates and
+        nobody needs this node's history rows.  Returns None when the pattern does not apply."""
+        if hist != 0:
+            return None
+        gain_node, filt = None, node
+        if isinstance(node, fx.Gain):
+            gain_node, filt = node, node.left.sig
+            if not isinstance(filt, fx.SingleCritFilter) or len(filt.outputs_with_ports) != 1:
+                return None
+        if not isinstance(filt, fx.SingleCritFilter) or not filt.get_state().enabled:
+            return None
+        src = filt.input.sig
+        if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
+            return None
+        try:
+            hertz, phase = self._control(src.hertz, 'hertz'), self._control(src.phase, 'phase')
+            cutoff = self._control(filt.cutoff, 'cutoff')
+            gain = self._control(gain_node.right, 'right') if gain_node is not None else None
+        except NotBatchable:
+            return None
+        widths_ok = (max(hertz.shape[1], phase.shape[1]) == channels and cutoff.shape[1] == channels
+                     and hertz.shape[1] in (1, channels) and phase.shape[1] in (1, channels)
+                     and (gain is None or gain.shape[1] in (1, channels)))
+        if not widths_ok:
+            return None
+        o = self.owner
+        result = torch.empty((self.N * self.K, channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        status = o._status_word(filt)
+        kind, btype = src.kind(), str(filt.type())
+        name = f'fused_osc_biquad[{kind},{btype}{",gain" if gain is not None else ""}]'
+        o._launch(name, lambda: _native.fused_osc_biquad(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT,
+                                                         hertz, phase, cutoff, gain, result, status=status),
+                  units=self.N * self.K * channels)
+        return result
 
     # -------------------------------------------------------------- filters
     def _filter(self, node: fx.SingleCritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:

@@ -61,12 +61,12 @@ class ShardedRenderer:
     [lo, hi); per-voice parameter rows are sliced once, at graph-build time."""
 
     def __init__(self, build: typing.Callable[[int, int], 'object'], total_voices: int, bus_channels: int,
-                 rate: int = 48000, group: int = 1, timer=None):
+                 rate: int = 48000, group: int = 1, timer=None, fuse: bool = True):
         from signals_amd.engine import BatchRenderer
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.lo, self.hi = shard_voices(total_voices, self.world, self.rank, group)
-        self.renderer = BatchRenderer(build(self.lo, self.hi), bus_channels, rate, timer=timer)
+        self.renderer = BatchRenderer(build(self.lo, self.hi), bus_channels, rate, timer=timer, fuse=fuse)
 
     def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
         return reduce_bus(self.renderer.render(position, block_frames, nblocks))

@@ -17,9 +17,10 @@ def _gpu():
     _native.lib()
 
 
-def batched(node, position, frames, blocks, channels):
+def batched(node, position, frames, blocks, channels, fuse=False):
+    """fuse=False: one kernel per node, bit-identical to the eager path; fuse=True: the engine's default"""
     from signals_amd.engine import BatchRenderer
-    return BatchRenderer(node, channels, RATE).render(position, frames, blocks).cpu().numpy()
+    return BatchRenderer(node, channels, RATE, fuse=fuse).render(position, frames, blocks).cpu().numpy()
 
 
 def c2_graph(g, V=None, bus=False):
@@ -78,7 +79,7 @@ def test_cascade_continuing_batches_and_fresh_start(golden):
         f2 = getattr(fx, second)(); f2.input = f1; f2.cutoff = fix(c['casc/cut2'])
         return f2
 
-    r = BatchRenderer(build(), 8, RATE)
+    r = BatchRenderer(build(), 8, RATE, fuse=False)
     parts = [r.render(0, 256, 1), r.render(256, 256, 2), r.render(768, 256, 1)]      # tails carried across batches
     got = torch.cat(parts).cpu().numpy()
     assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
@@ -148,7 +149,7 @@ def test_driver_steps_like_the_callback(golden):
     out = d.render(4)
     assert d.frame_position == 1024 and d.tell() == 4 and out.shape == (1024, 1)
     d.seek(0)
-    assert np.array_equal(out[:256], d.pull())
+    assert maxerr(out[:256], d.pull()) < 2e-8          # render() may fuse Filter(Osc)xGain; pull() is the eager path
     stereo = BlockDriver(); stereo.get_state().channels = 2; stereo.input = c2_graph(g, bus=True)
     s = stereo.render(1)
     assert s.shape == (256, 2) and np.array_equal(s[:, 0], s[:, 1])       # (N,1) reply broadcast to 2 channels
@@ -263,3 +264,43 @@ def test_c5_config_vs_oracle():
     ref = R.mix_matrix(lp, M.astype(np.float32).astype(np.float64))
     assert maxerr(got, f32(ref)) < 2e-6
     assert np.array_equal(got, stream(build(), 0, N, K, V))
+
+
+def test_fused_voice_chain_vs_golden_and_unfused(golden):
+    """sig_fused_osc_biquad: Filter(Osc) [x Gain] in one launch; closer to the f64 reference than the
+    materialised path (no f32 rounding between the stages), within 1e-6 of it either way."""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    for tag, pos0 in (('p0', 0), ('p1h', HOUR)):
+        timer = KernelTimer()
+        got = BatchRenderer(c2_graph(g), 32, RATE, timer=timer, fuse=True).render(pos0, 256, 4).cpu().numpy()
+        torch.cuda.synchronize()
+        assert list(timer.summary()) == ['fused_osc_biquad[Sine,lp,gain]']
+        assert maxerr(got, f32(g[f'c2/{tag}'])) < 2e-8
+        assert maxerr(got, batched(c2_graph(g), pos0, 256, 4, 32)) < 2e-8
+    f = golden('filter')
+    for fname, oname in (('LowPass', 'Sine'), ('HighPass', 'Sawtooth'), ('HighPass', 'Sine'), ('LowPass', 'Sawtooth')):
+        for pos in (0, 50, 256, HOUR):
+            flt = getattr(fx, fname)(); flt.input = mkosc(oname, f['filt/hertz'], f['filt/phase']); flt.cutoff = fix(f['filt/cutoff'])
+            got = batched(flt, pos, 256, 1, 16, fuse=True)
+            assert maxerr(got, f32(f[f'filt/{fname}/{oname}/p{pos}'])) < 3e-7, (fname, oname, pos)
+    # odd widths / block sizes, Square and Triangle sources, scalar gain
+    rng = np.random.default_rng(9)
+    for V, N, K, kind in ((3, 33, 5, 'Square'), (130, 100, 3, 'Triangle'), (64, 512, 2, 'Sine')):
+        hz, ph, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(200, 8000, (1, V))
+
+        def build():
+            flt = fx.HighPass(); flt.input = mkosc(kind, hz, ph); flt.cutoff = fix(cut)
+            gn = fx.Gain(); gn.left = flt; gn.right = fix([[0.5]])
+            return gn
+        assert maxerr(batched(build(), 77, N, K, V, fuse=True), batched(build(), 77, N, K, V)) < 3e-7, (V, N, K, kind)
+    # a second consumer of the oscillator forbids fusing it away
+    o = mkosc('Sine', g['c2/hertz'], g['c2/phase'])
+    flt = fx.LowPass(); flt.input = o; flt.cutoff = fix(g['c2/cutoff'])
+    mx = fx.Mix(); mx.left = flt; mx.right = o; mx.mix = fix([[0.5]])
+    timer = KernelTimer()
+    got = BatchRenderer(mx, 32, RATE, timer=timer, fuse=True).render(0, 256, 2).cpu().numpy()
+    torch.cuda.synchronize()
+    assert not any(k.startswith('fused') for k in timer.summary())
+    assert np.array_equal(got, stream(mx, 0, 256, 2, 32))

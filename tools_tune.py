@@ -41,3 +41,43 @@ if __name__ == '__main__' and os.environ.get('TUNE') == 'osc':
     for kind in ('Sine', 'Square', 'Sawtooth', 'Triangle'):
         ms, gbs = time_osc(256, kind)
         print(f'osc {kind}: {ms*1e3:.1f} us {gbs:.0f} GB/s', flush=True)
+
+def time_bus(K, reps=20, C=2):
+    x = torch.rand((K * N, V), device='cuda') * 2 - 1
+    rng = np.random.default_rng(0)
+    th = rng.uniform(0, np.pi / 2, V)
+    g = torch.tensor(np.stack([np.cos(th), np.sin(th)])[:C], device='cuda') if C else None
+    out = torch.empty((K * N, max(C, 1)), device='cuda')
+    for _ in range(3): _native.sum_bus(x, g, out)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): _native.sum_bus(x, g, out)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    return ms, 4 * K * N * V / ms / 1e6
+
+if __name__ == '__main__' and os.environ.get('TUNE') == 'bus':
+    for C in (2, 0):
+        ms, gbs = time_bus(256, C=C)
+        print(f'bus C={C}: {ms*1e3:.1f} us {gbs:.0f} GB/s', flush=True)
+
+
+def time_fused(K, reps=20, gain=True):
+    rng = np.random.default_rng(0)
+    mk = lambda lo, hi: torch.tensor(rng.uniform(lo, hi, (1, V)), device='cuda')
+    hz, ph, cut, g = mk(55, 1760), mk(0, 1), mk(200, 8000), mk(0, 1)
+    out = torch.empty((K * N, V), device='cuda')
+    f = lambda: _native.fused_osc_biquad('Sine', 'lp', 48000, 0, N, K, 100, hz, ph, cut, g if gain else None, out)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+if __name__ == '__main__' and os.environ.get('TUNE') == 'fused':
+    for K in (256, 1024):
+        ms = time_fused(K)
+        print(f'fused vpt={os.environ.get("SIG_FUSED_VPT","default")} K={K}: {ms*1e3:.1f} us  {K*N*V/ms/1e3:.0f} Msamples/s', flush=True)
