@@ -142,16 +142,32 @@ def main():
                                             rate=RATE, timer=timer, fuse=fuse)
         assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
         pos = args.position
-        for _ in range(warmup):
-            renderer.render(pos, N, K)
+        pending = None
+
+        def step():
+            # (K*N, 2) f32 bus: local render, then the RCCL all-reduce of THIS batch is left in flight on
+            # RCCL's stream while the next batch renders; it is waited for one step later (and at the fence)
+            nonlocal pos, pending
+            bus, work = renderer.render_async(pos, N, K)
             pos += N * K
+            if pending is not None:
+                pending.wait()
+            pending = work
+            return bus
+
+        for _ in range(warmup):
+            step()
+        if pending is not None:
+            pending.wait()
+            pending = None
         fence()
         if timer:
             timer.reset()
         t0 = time.perf_counter()
         for _ in range(steps):
-            bus = renderer.render(pos, N, K)             # (K*N, 2) f32: local render + RCCL all-reduce of the bus
-            pos += N * K
+            bus = step()
+        if pending is not None:
+            pending.wait()
         fence()
         dt = time.perf_counter() - t0
         runtime.check_status()
@@ -198,6 +214,31 @@ def main():
     if not args.single_mode:
         other = measure(fuse=args.materialised, steps=max(3, args.steps // 2), warmup=min(2, args.warmup))
 
+    latency = None
+    if world == 1 and not args.single_mode:
+        # latency mode: ONE 256-frame block per request, as a real-time sink would pull it
+        from signals_amd.chain.driver import BlockDriver
+        from signals_amd.engine import BatchRenderer
+        graph = build_graph(params, 0, V)
+        eng = BatchRenderer(graph, 2, RATE)
+        drv = BlockDriver(rate=RATE, blocksize=N)
+        drv.get_state().channels = 2
+        drv.input = build_graph(params, 0, V)
+        latency = {}
+        for name, fn in (('engine_one_block_per_launch', lambda i: eng.render(i * N, N, 1)),
+                         ('eager_pull_one_block', lambda i: drv.input.request(
+                             __import__('signals_amd.chain', fromlist=['BlockLoc']).BlockLoc(
+                                 position=i * N, rate=RATE, shape=__import__('signals_amd.chain', fromlist=['Shape']).Shape(N, 2))))):
+            for i in range(20):
+                fn(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(20, 220):
+                fn(i)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / 200 * 1e6
+            latency[name] = {'us_per_block': us, 'Msamples_per_s': V * N / us, 'x_realtime': (N / RATE * 1e6) / us}
+
     if rank == 0:
         def describe(fused):
             return ('fused voice chain: sig_fused_osc_biquad (Sine->LowPass->Gain in one launch, oscillator and filter '
@@ -224,10 +265,12 @@ def main():
         if other is not None:
             other['schedule'] = describe(args.materialised)
             line['alt_schedule'] = other
+        if latency is not None:
+            line['latency_mode'] = latency
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(params, V, N)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

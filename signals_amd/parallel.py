@@ -34,7 +34,12 @@ def shard_voices(total: int, world: int, rank: int, group: int = 1) -> tuple[int
 def init_process_group() -> tuple[int, int]:
     """(rank, world) from the torchrun environment; RCCL when this process has a GPU, gloo otherwise."""
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('SIG_FORCE_DIST') == '1'          # exercise the RCCL path on a single rank (tests)
+    if force and world == 1:
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if torch.cuda.is_available():
             local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -44,14 +49,17 @@ def init_process_group() -> tuple[int, int]:
     return rank, world
 
 
-def reduce_bus(bus: torch.Tensor, dst: typing.Optional[int] = None) -> torch.Tensor:
-    """Sum the per-shard bus in place: all-reduce (every rank gets the mix) or reduce to `dst`."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def reduce_bus(bus: torch.Tensor, dst: typing.Optional[int] = None, async_op: bool = False):
+    """Sum the per-shard bus in place: all-reduce (every rank gets the mix) or reduce to `dst`.
+    `async_op=True` returns `(bus, work)`: the collective runs on RCCL's own stream and overlaps whatever
+    the render stream does next; call `work.wait()` (None when nothing was launched) before reading `bus`."""
+    work = None
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('SIG_FORCE_DIST') == '1'):
         if dst is None:
-            dist.all_reduce(bus, op=dist.ReduceOp.SUM)
+            work = dist.all_reduce(bus, op=dist.ReduceOp.SUM, async_op=async_op)
         else:
-            dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM)
-    return bus
+            work = dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, async_op=async_op)
+    return (bus, work) if async_op else bus
 
 
 class ShardedRenderer:
@@ -70,3 +78,8 @@ class ShardedRenderer:
 
     def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
         return reduce_bus(self.renderer.render(position, block_frames, nblocks))
+
+    def render_async(self, position: int, block_frames: int, nblocks: int):
+        """(bus, work): the bus all-reduce of this batch overlaps the next batch's kernels; `work.wait()`
+        (if not None) before the bus is read."""
+        return reduce_bus(self.renderer.render(position, block_frames, nblocks), async_op=True)
