@@ -13,6 +13,7 @@
 // quotient n/rate (IEEE f64 divide) is computed 64 rows at a time, one row per lane, and broadcast with
 // v_readlane.  f64-VALU-bound: ~(15 osc + 9 filter + 2) x (N+c)/N f64-rate ops per voice-sample.
 #include <cstdlib>
+#include <type_traits>
 
 #include "sig_biquad.h"
 #include "sig_osc.h"
@@ -71,29 +72,36 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
     if (!ok && live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
     float* dst = a.out + (b * a.N - c) * a.out_ld + vc;                      // rows < c are never stored
-    for (int r0 = 0; r0 < total; r0 += SIG_WAVE) {
-        const double q_lane = (double)(n0 + r0 + lane) / a.rate;             // osc.py:32, one row per lane
-        const int lim = (total - r0 < SIG_WAVE) ? total - r0 : SIG_WAVE;
-        for (int j = 0; j < lim; ++j) {
-            const double t_s = sig_readlane_f64(q_lane, j);
-            const int r = r0 + j;
-            float y32[VPT];
+
+    // rows [r_begin, r_end): STORE=false warms the filter up (context rows), STORE=true keeps the block
+    auto walk = [&](int r_begin, int r_end, auto store_tag) {
+        constexpr bool STORE = decltype(store_tag)::value;
+        for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
+            const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
+            const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
+#pragma unroll 2
+            for (int j = 0; j < lim; ++j) {
+                const double t_s = sig_readlane_f64(q_lane, j);
+                float y32[VPT];
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const double t = t_s * hz[i] + ph[i];
-                const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                        : sig_osc::osc_wave<KIND, double>(t);
-                const double y = q[i].b0 * x + z0[i];                         // scipy _sosfilt order, contract off
-                z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
-                z1[i] = q[i].b2 * x - q[i].a2 * y;
-                y32[i] = (float)(GAIN ? y * g[i] : y);
-            }
-            if (r >= c && live) {
-                Vec o; put(o, y32);
-                *reinterpret_cast<Vec*>(dst + (int64_t)r * a.out_ld) = o;
+                for (int i = 0; i < VPT; ++i) {
+                    const double t = t_s * hz[i] + ph[i];
+                    const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                            : sig_osc::osc_wave<KIND, double>(t);
+                    const double y = q[i].b0 * x + z0[i];                     // scipy _sosfilt order, contract off
+                    z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
+                    z1[i] = q[i].b2 * x - q[i].a2 * y;
+                    if (STORE) y32[i] = (float)(GAIN ? y * g[i] : y);
+                }
+                if (STORE && live) {
+                    Vec o; put(o, y32);
+                    *reinterpret_cast<Vec*>(dst + (int64_t)(r0 + j) * a.out_ld) = o;
+                }
             }
         }
-    }
+    };
+    walk(0, c, std::false_type{});
+    walk(c, total, std::true_type{});
 }
 
 int fused_variant() {
@@ -107,7 +115,8 @@ int launch_fused(FusedArgs a, hipStream_t stream)
     auto ok = [&](int vpt) {
         return (a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0);
     };
-    int vpt = fused_variant() ? fused_variant() : 2;
+    int vpt = fused_variant() ? fused_variant() : 4;
+    while (vpt > 1 && !ok(vpt)) vpt >>= 1;
     if (!ok(vpt)) vpt = 1;
     const int span = SIG_WAVE * vpt;
     a.voice_tiles = (a.voices + span - 1) / span;

@@ -28,23 +28,35 @@ __device__ __forceinline__ double sin_poly(double x) {
 }
 
 // np.sin(t * 2 * np.pi) reproduced including the reference's own argument rounding:
-//   a = fl(fl(2t) * fl(pi)) is what numpy hands to libm.  a = 2*pi*t + delta with
-//   delta = -(fl(2t)*fl(pi) - a) - 2t*(pi - fl(pi)); the first term is exact via fma.
-// So sin(a) = sin(2*pi*frac(t) + delta), evaluated with frac(t) exact in f64.
+//   a = fl(fl(2t) * fl(pi)) = fl(t * 2fl(pi)) is what numpy hands to libm;  a = 2*pi*t - s  with
+//   s = (t*2fl(pi) - a) + t*2(pi - fl(pi)); the first term is exact via fma.
+// So sin(a) = sin(2*pi*(t - K/2) + pi*K - s) with K = rint(2t): rq = t - K/2 is exact in f64, |rq| <= 1/4,
+// and an odd K flips the sign.  K and its parity come from one magic-number add (RNE to an integer in the
+// low mantissa bits), valid for |t| < 2^50 cycles -- beyond that f64 has no fraction bits left anyway.
+constexpr double kRoundMagic = 6755399441055744.0;      // 1.5 * 2^52
+constexpr double kTwoPi = 2.0 * kPi;                     // exact doubling of fl(pi)
+constexpr double kTwoPiTail = 2.0 * kPiTail;
+
+struct SinePhase { double rq; double s; unsigned flip; };   // quarter-range revolutions, -(delta), sign bit
+
+__device__ __forceinline__ SinePhase sine_phase(double t) {
+    SinePhase p;
+    const double a = t * kTwoPi;
+    const double e = fma(t, kTwoPi, -a);                // a + e == t * 2fl(pi) exactly
+    p.s = fma(t, kTwoPiTail, e);
+    const double u = (t + t) + kRoundMagic;             // low mantissa bits = rint(2t)
+    const double k = u - kRoundMagic;                   // exact
+    p.rq = fma(k, -0.5, t);                             // exact, |rq| <= 0.25
+    p.flip = ((unsigned)__double2loint(u) & 1u) << 31;  // parity of K
+    return p;
+}
+
+// f64 store path (block-rate control values): polynomial on [-pi/2, pi/2], ~1 ulp(f64)
 __device__ __forceinline__ double osc_sine(double t) {
-    const double t2 = t * 2.0;
-    const double a = t2 * kPi;
-    const double e = fma(t2, kPi, -a);
-    const double delta = -e - t2 * kPiTail;
-    const double r = t - rint(t);                       // exact, |r| <= 0.5
-    const double k = rint(r + r);                       // -1, 0, +1: half-turns to remove
-    const double rq = fma(k, -0.5, r);                  // exact, |rq| <= 0.25
-    const double x = fma(rq, kTwoPiHi, fma(rq, kTwoPiLo, delta));
+    const SinePhase p = sine_phase(t);
+    const double x = fma(p.rq, kTwoPiHi, fma(p.rq, kTwoPiLo, -p.s));
     const double y = sin_poly(x);
-    // sin(theta + pi*k) = -sin(theta) for odd k: flip the sign bit, branch-free
-    const int flip = (k != 0.0) ? (int)0x80000000 : 0;
-    return __hiloint2double(__double2hiint(y) ^ flip, __double2loint(y));
-    // domain: |t| < 2^51 cycles (beyond that f64 has no fraction bits left)
+    return __hiloint2double(__double2hiint(y) ^ (int)p.flip, __double2loint(y));
 }
 
 __device__ __forceinline__ double osc_square(double t) {       // osc.py:48-49
@@ -62,20 +74,13 @@ __device__ __forceinline__ double osc_triangle(double t) {     // osc.py:60-62
 
 // f32 store path of Sine: same exact phase reduction, then the hardware sine (v_sin_f32 takes
 // REVOLUTIONS; measured max |err| 1.07e-7 on [-0.25, 0.25]).  Total error vs the reference
-// <= 1.3e-7 (bar 1e-6), at 15 f64-rate ops per sample instead of 27, which is what makes the kernel
-// HBM-write-bound instead of f64-VALU-bound.
+// <= 1.3e-7 (bar 1e-6), at ~13 f64-rate ops per sample instead of 27, which is what makes the oscillator
+// kernel HBM-write-bound instead of f64-VALU-bound.
 constexpr double kInvTwoPi = 0.15915494309189535;
 __device__ __forceinline__ float osc_sine_f32(double t) {
-    const double t2 = t + t;
-    const double a = t2 * kPi;
-    const double e = fma(t2, kPi, -a);                  // a + e == t2 * fl(pi) exactly
-    const double s = fma(t2, kPiTail, e);               // -(delta): how far numpy's argument is from 2*pi*t
-    const double r = t - rint(t);
-    const double k = rint(r + r);
-    const double rq = fma(k, -0.5, r);                  // exact, |rq| <= 0.25
-    const float rev = (float)fma(s, -kInvTwoPi, rq);
-    const float y = __builtin_amdgcn_sinf(rev);
-    return __uint_as_float(__float_as_uint(y) ^ ((k != 0.0) ? 0x80000000u : 0u));
+    const SinePhase p = sine_phase(t);
+    const float rev = (float)fma(p.s, -kInvTwoPi, p.rq);
+    return __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(rev)) ^ p.flip);
 }
 
 template <int KIND, typename OUT> __device__ __forceinline__ OUT osc_wave(double t) {
