@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1]): per GPU a 1024-voice
 `Fixed -> Sine -> LowPass -> Gain -> SumBus(stereo)` graph built through the node API and rendered by
-the batched engine, one step = one batch of `--blocks` consecutive 256-frame blocks of synthetic
+the batched engine, one step = one batch of `--blocks` (default 1024) consecutive 256-frame blocks of synthetic
 parameters (numpy default_rng(0): hertz U(55,1760), phase U(0,1), cutoff U(200,8000), gain U(0,1)/V,
 pan theta U(0,pi/2)), already resident in HBM.  With N > 1 GPUs every rank renders its own 1024 voices
 (weak scaling, no data-path traffic) and the stereo bus is summed across ranks with one RCCL
@@ -35,7 +35,9 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8
 # algorithmic HBM bytes per voice-sample, f32 storage, every node output written once and read once
 # per consumer (SURVEY.md §8d, C2 = 24 B over the four kernels)
 ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
-              'fused_osc_biquad': 4}      # fused chain: only the f32 store reaches HBM
+              'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
+              'fused_voice_bus': 2 * 2 * 8 / 256 + 2 * 4 / 1024}   # f64 tile partials (written, re-read) + f32 stereo bus
+F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 25, 'fused_voice_bus': 26}   # f64-rate VALU instructions per (voice, row), ISA count
 
 
 def synth_params(total_voices: int):
@@ -104,7 +106,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--blocks', type=int, default=256, help='256-frame blocks per batch (one step)')
+    ap.add_argument('--blocks', type=int, default=1024, help='256-frame blocks per batch (one step)')
     ap.add_argument('--voices', type=int, default=1024, help='voices per GPU')
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--position', type=int, default=0)
@@ -198,14 +200,17 @@ def main():
                                'traffic': traffic,
                                'algo_bytes_per_voice_sample': kernels[dom]['algo_bytes_per_voice_sample'],
                                'avg_launch_ms': kernels[dom]['avg_ms']}
-            if dom.startswith('fused_osc_biquad'):
-                # f64-VALU-bound kernel: 25 f64-rate instructions per (voice, row) update (12 phase + 3 cvt + 8
-                # recurrence + gain + compare, counted in the ISA), (N+c)/N updates per stored
-                # sample; peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz
+            if dom.split('[')[0] in F64_INSTR_PER_UPDATE:
+                # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
+                # the meaningful ceiling is the f64 vector issue rate.  Instructions per (voice, row) update are
+                # counted in the ISA; (N+c)/N updates per stored sample (context rows recomputed);
+                # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
                 upd = (summ[dom]['units'] / summ[dom]['calls']) * (N + 100) / N
-                ach = 25 * upd / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
+                ach = F64_INSTR_PER_UPDATE[dom.split('[')[0]] * upd / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
                 res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
                                                'frac': ach / 39.3}
+                res['roofline']['note'] = ('this kernel is f64-VALU-bound, not HBM-bound: see valu_f64; the HBM-bound '
+                                           'node-materialised schedule is reported under alt_schedule')
             res['kernels'] = kernels
         return res
 
@@ -241,8 +246,8 @@ def main():
 
     if rank == 0:
         def describe(fused):
-            return ('fused voice chain: sig_fused_osc_biquad (Sine->LowPass->Gain in one launch, oscillator and filter '
-                    'outputs never stored) + sig_sum_bus' if fused else
+            return ('fused voice chain + bus: sig_fused_voice_bus (Sine->LowPass->Gain->SumBus in one chain launch plus a '
+                    'fixed-order tile sum; no per-voice sample touches HBM)' if fused else
                     'node-materialised: one kernel per node (osc_bank, biquad_coldstart, elementwise[Gain], sum_bus), '
                     'every edge f32 in HBM (24 B/voice-sample, SURVEY.md 8d)')
         line = {

@@ -135,6 +135,20 @@ int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t posi
                          const double* gain, int32_t gain_stride,
                          float* out, int64_t out_ld, int32_t* status, void* stream);
 
+/* Fused voice chain + sum bus:  out[n,c] = sum_v bus_gains[c,v] * ([gain[v] *] Filter(Osc)[n,v])
+ * (bus_gains == NULL: bus_channels == 1, plain sum).  Nothing per-voice touches HBM.  Two launches inside:
+ * the chain kernel writes per-voice-tile f64 partials into `workspace` (device, at least
+ * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second
+ * kernel adds the tiles in a fixed order and rounds to f32.  Deterministic; no atomics. */
+int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
+int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                        const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                        const double* cutoff, int32_t cutoff_stride,
+                        const double* gain, int32_t gain_stride,
+                        const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                        double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,8 @@ EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
-           'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad')
+           'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
+           'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace')
 
 
 class NativeError(RuntimeError):
@@ -64,6 +65,11 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_osc_biquad.restype = ctypes.c_int
         L.sig_fused_osc_biquad.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                            dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
+        L.sig_fused_voice_bus_workspace.restype = ctypes.c_int64
+        L.sig_fused_voice_bus_workspace.argtypes = [i32, i64, i32]
+        L.sig_fused_voice_bus.restype = ctypes.c_int
+        L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                          dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         if L.sig_abi_version() != 1:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -250,4 +256,34 @@ def fused_osc_biquad(kind: str, btype: str, rate: int, position: int, block_fram
                                       voices, *ptrs, out.data_ptr(), out.stride(0),
                                       status.data_ptr() if status is not None else None, _stream(out)),
            'sig_fused_osc_biquad')
+    return out
+
+
+def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                    voices: int, hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
+                    gain: torch.Tensor | None, bus_gains: torch.Tensor | None, out: torch.Tensor,
+                    workspace: torch.Tensor | None = None, status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (nblocks*block_frames, bus_channels) f32 <- sum over voices of pan * [gain *] Filter(Osc)"""
+    _gpu(hertz, phase, cutoff, gain, bus_gains, out, status)
+    _audio(out, 'fused bus out')
+    rows, bus = out.shape
+    if out.dtype != torch.float32 or rows != block_frames * nblocks:
+        raise NativeError(f'fused bus out must be float32 ({block_frames * nblocks}, C), got {tuple(out.shape)} {out.dtype}')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    gp, gld = None, 0
+    if bus_gains is not None:
+        if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus, voices) or bus_gains.stride(1) != 1:
+            raise NativeError(f'bus gains must be float64 ({bus},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+        gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+    need = lib().sig_fused_voice_bus_workspace(voices, rows, bus)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    _check(lib().sig_fused_voice_bus(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
+                                     voices, *ptrs, gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
+                                     status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_fused_voice_bus')
     return out

@@ -79,7 +79,6 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
         for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
             const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
             const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
-#pragma unroll 2
             for (int j = 0; j < lim; ++j) {
                 const double t_s = sig_readlane_f64(q_lane, j);
                 float y32[VPT];
@@ -102,6 +101,172 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
     };
     walk(0, c, std::false_type{});
     walk(c, total, std::true_type{});
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused voice chain + bus: the same chain, but instead of storing each voice the wave reduces its
+// 64*VPT voices into the C bus channels:  partial[tile][row][c] = sum_v pan[c][v] * (gain[v] * y[v]).
+// Lanes are voices, so a row's sum is a cross-lane sum; doing it per row with a butterfly would cost as
+// much as the chain itself, so rows are staged kGroup at a time in a wave-private LDS tile
+// [pair = row*C + c][lane] (row stride 65 doubles: conflict-free for the transposed read) and reduced by
+// lane = pair: 16 LDS reads + 2 shuffles per lane per kGroup rows.  A second tiny kernel adds the voice
+// tiles in a fixed order (deterministic, no atomics) and rounds to f32.  Nothing but parameters is read
+// from HBM and nothing but the bus is written: 8*C B per frame instead of 4 B per voice-sample.
+constexpr int kPairs = 16;                 // (row, channel) pairs reduced per flush
+constexpr int kTileStride = 65;            // doubles
+
+struct BusArgs { const double* pan; int64_t pan_ld; double* partials; int64_t rows; };
+
+template <int KIND, int VPT, bool GAIN, int C>
+__global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusArgs bus)
+{
+    constexpr int R = kPairs / C;          // rows per flush
+    __shared__ double lds[4][kPairs * kTileStride];
+    const int lane = threadIdx.x & 63;
+    double* tile = lds[threadIdx.x >> 6];
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int vt = (int)(item % a.voice_tiles);
+    const int64_t b = item / a.voice_tiles;
+    if (b >= a.K) return;                                                     // wave-uniform
+    const int v0 = (vt * SIG_WAVE + lane) * VPT;
+
+    const int64_t p_b = a.position + b * a.N;
+    const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+    const int64_t n0 = p_b - c;
+    const int total = c + a.N;
+
+    Biquad q[VPT];
+    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], w[C][VPT];
+    bool ok = true, any_live = false;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const bool live = v0 + i < a.voices;
+        const int v = live ? v0 + i : 0;                                       // dead lanes shadow voice 0 ...
+        any_live |= live;
+        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q[i]) || !live;
+        hz[i] = a.hertz[(int64_t)v * a.hs];
+        ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+        const double gn = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0
+            w[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * gn : gn) : 0.0;   // pan * gain, once per voice
+        z0[i] = 0.0; z1[i] = 0.0;
+    }
+    if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+
+    double* dst = bus.partials + ((int64_t)vt * bus.rows + b * a.N) * C;      // [tile][row][c], row 0 = block start
+    const int pair = lane & (kPairs - 1), quarter = lane >> 4;
+
+    auto flush = [&](int row_first, int nrows) {                               // rows [row_first, row_first+nrows) of the block
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += tile[pair * kTileStride + quarter * 16 + k];
+        s += sig_shfl_xor_f64(s, 16);
+        s += sig_shfl_xor_f64(s, 32);
+        if (lane < nrows * C) dst[(int64_t)row_first * C + lane] = s;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    auto walk = [&](int r_begin, int r_end, auto store_tag) {
+        constexpr bool STORE = decltype(store_tag)::value;
+        int staged = 0, first = r_begin - c;
+        for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
+            const double q_lane = (double)(n0 + r0 + lane) / a.rate;
+            const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
+            for (int j = 0; j < lim; ++j) {
+                const double t_s = sig_readlane_f64(q_lane, j);
+                double acc[C];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0;
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const double t = t_s * hz[i] + ph[i];
+                    const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                            : sig_osc::osc_wave<KIND, double>(t);
+                    const double y = q[i].b0 * x + z0[i];
+                    z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
+                    z1[i] = q[i].b2 * x - q[i].a2 * y;
+                    if (STORE) {
+#pragma unroll
+                        for (int ch = 0; ch < C; ++ch) acc[ch] = fma(w[ch][i], y, acc[ch]);
+                    }
+                }
+                if (STORE) {
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) tile[(staged * C + ch) * kTileStride + lane] = acc[ch];
+                    if (++staged == R) { flush(first, R); first += R; staged = 0; }
+                }
+            }
+        }
+        if (STORE && staged) flush(first, staged);
+    };
+    walk(0, c, std::false_type{});
+    walk(c, total, std::true_type{});
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restrict__ partials, int tiles, int64_t rows,
+                                                           float* __restrict__ out, int64_t out_ld)
+{
+    const int64_t n = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int t = 0; t < tiles; ++t) s += partials[(int64_t)t * n + i];       // fixed order
+        out[(i / C) * out_ld + (i % C)] = (float)s;
+    }
+}
+
+int pick_vpt(int voices) {
+    int vpt = 4;
+    const char* e = getenv("SIG_FUSED_VPT");
+    if (e) vpt = atoi(e);
+    if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 4;
+    return vpt;                                                               // no alignment needs: nothing per-voice is stored
+}
+
+template <int KIND, bool GAIN, int C>
+int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
+{
+    const int vpt = pick_vpt(a.voices);
+    a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+    const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    switch (vpt) {
+        case 1: fused_voice_bus_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 2: fused_voice_bus_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        default: fused_voice_bus_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+    }
+    int err = sig_launch_status();
+    if (err) return err;
+    const int64_t n = bus.rows * C;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    bus_partials_kernel<C><<<(unsigned)g, 256, 0, stream>>>(bus.partials, a.voice_tiles, bus.rows, out, out_ld);
+    return sig_launch_status();
+}
+
+template <int KIND, bool GAIN>
+int dispatch_bus_channels(int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
+{
+    switch (C) {
+        case 1: return launch_voice_bus<KIND, GAIN, 1>(a, bus, out, out_ld, s);
+        case 2: return launch_voice_bus<KIND, GAIN, 2>(a, bus, out, out_ld, s);
+        case 4: return launch_voice_bus<KIND, GAIN, 4>(a, bus, out, out_ld, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+template <bool GAIN>
+int dispatch_bus_kind(int kind, int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
+{
+    switch (kind) {
+        case SIG_OSC_SINE: return dispatch_bus_channels<SIG_OSC_SINE, GAIN>(C, a, bus, out, out_ld, s);
+        case SIG_OSC_SQUARE: return dispatch_bus_channels<SIG_OSC_SQUARE, GAIN>(C, a, bus, out, out_ld, s);
+        case SIG_OSC_SAWTOOTH: return dispatch_bus_channels<SIG_OSC_SAWTOOTH, GAIN>(C, a, bus, out, out_ld, s);
+        case SIG_OSC_TRIANGLE: return dispatch_bus_channels<SIG_OSC_TRIANGLE, GAIN>(C, a, bus, out, out_ld, s);
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 int fused_variant() {
@@ -162,4 +327,34 @@ extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, i
                 out, out_ld, 0, status};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
+}
+
+extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)
+{
+    // worst case: one tile per 64 voices (VPT = 1)
+    const int64_t tiles = (voices + SIG_WAVE - 1) / SIG_WAVE;
+    return tiles * rows * bus_channels * (int64_t)sizeof(double);
+}
+
+extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                   int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                   const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                   const double* cutoff, int32_t cutoff_stride,
+                                   const double* gain, int32_t gain_stride,
+                                   const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                   double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                nullptr, 0, 0, status};
+    BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return gain ? dispatch_bus_kind<true>(osc_kind, bus_channels, a, bus, out, out_ld, s)
+                : dispatch_bus_kind<false>(osc_kind, bus_channels, a, bus, out, out_ld, s);
 }

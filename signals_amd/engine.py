@@ -75,10 +75,11 @@ class KernelTimer:
 class BatchRenderer:
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
-                 fuse: bool = True):
+                 fuse: bool = True, fuse_bus: bool = True):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad).  Off = one kernel per node, bit-identical to the eager path."""
         self.fuse = fuse
+        self.fuse_bus = fuse and fuse_bus           # also fold a SumBus on top of the chain into the launch
         self.node = node
         self.channels = channels
         self.rate = rate
@@ -86,6 +87,7 @@ class BatchRenderer:
         self._tails: dict[Emitter, tuple[int, torch.Tensor]] = {}    # node -> (end position, last <=100 rows)
         self._stream_end: int | None = None
         self._status: dict[Emitter, runtime.StatusWord] = {}
+        self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
 
     # ------------------------------------------------------------------ public
     def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
@@ -310,13 +312,23 @@ class _Batch:
 
     # -------------------------------------------------------------- fusion
     def _try_fuse(self, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
-        """[Gain(] LowPass|HighPass(Osc) [)] -> one launch, when nothing else reads the intermediates and
-        nobody needs this node's history rows.  Returns None when the pattern does not apply."""
+        """[SumBus(] [Gain(] LowPass|HighPass(Osc) [)] [)] -> one launch, when nothing else reads the
+        intermediates and nobody needs this node's history rows.  None when the pattern does not apply."""
         if hist != 0:
             return None
-        gain_node, filt = None, node
-        if isinstance(node, fx.Gain):
-            gain_node, filt = node, node.left.sig
+        bus_node, top = None, node
+        if isinstance(node, ext.SumBus):
+            if not self.owner.fuse_bus:
+                return None
+            bus_node, top = node, node.input.sig
+            if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
+                return None
+            if node.channels not in (1, 2, 4):
+                return None
+            channels = node.input.channels
+        gain_node, filt = None, top
+        if isinstance(top, fx.Gain):
+            gain_node, filt = top, top.left.sig
             if not isinstance(filt, fx.SingleCritFilter) or len(filt.outputs_with_ports) != 1:
                 return None
         if not isinstance(filt, fx.SingleCritFilter) or not filt.get_state().enabled:
@@ -336,13 +348,29 @@ class _Batch:
         if not widths_ok:
             return None
         o = self.owner
-        result = torch.empty((self.N * self.K, channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        rows = self.N * self.K
         status = o._status_word(filt)
         kind, btype = src.kind(), str(filt.type())
-        name = f'fused_osc_biquad[{kind},{btype}{",gain" if gain is not None else ""}]'
-        o._launch(name, lambda: _native.fused_osc_biquad(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT,
-                                                         hertz, phase, cutoff, gain, result, status=status),
-                  units=self.N * self.K * channels)
+        tag = f'{kind},{btype}{",gain" if gain is not None else ""}'
+        if bus_node is not None:
+            pan = bus_node.resident_gains()
+            if pan is not None and pan.shape[1] != channels:
+                return None
+            result = torch.empty((rows, bus_node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
+            need = _native.lib().sig_fused_voice_bus_workspace(channels, rows, bus_node.channels) // 8
+            if o._workspace is None or o._workspace.numel() < need:
+                o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
+            o._launch(f'fused_voice_bus[{tag}]',
+                      lambda: _native.fused_voice_bus(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT, channels,
+                                                      hertz, phase, cutoff, gain, pan, result,
+                                                      workspace=o._workspace, status=status),
+                      units=rows * channels)
+            return result
+        result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        o._launch(f'fused_osc_biquad[{tag}]',
+                  lambda: _native.fused_osc_biquad(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT,
+                                                   hertz, phase, cutoff, gain, result, status=status),
+                  units=rows * channels)
         return result
 
     # -------------------------------------------------------------- filters

@@ -274,7 +274,7 @@ def test_fused_voice_chain_vs_golden_and_unfused(golden):
     g = golden('c2')
     for tag, pos0 in (('p0', 0), ('p1h', HOUR)):
         timer = KernelTimer()
-        got = BatchRenderer(c2_graph(g), 32, RATE, timer=timer, fuse=True).render(pos0, 256, 4).cpu().numpy()
+        got = BatchRenderer(c2_graph(g), 32, RATE, timer=timer, fuse=True).render(pos0, 256, 4).cpu().numpy()      # no bus on top
         torch.cuda.synchronize()
         assert list(timer.summary()) == ['fused_osc_biquad[Sine,lp,gain]']
         assert maxerr(got, f32(g[f'c2/{tag}'])) < 2e-8
@@ -304,3 +304,40 @@ def test_fused_voice_chain_vs_golden_and_unfused(golden):
     torch.cuda.synchronize()
     assert not any(k.startswith('fused') for k in timer.summary())
     assert np.array_equal(got, stream(mx, 0, 256, 2, 32))
+
+
+def test_fused_voice_bus_vs_oracle_and_unfused(golden):
+    """sig_fused_voice_bus: SumBus(Gain(Filter(Osc))) in one chain launch + a fixed-order tile sum"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    for tag, pos0 in (('p0', 0), ('p1h', HOUR)):
+        timer = KernelTimer()
+        got = BatchRenderer(c2_graph(g, bus=True), 1, RATE, timer=timer).render(pos0, 256, 4).cpu().numpy()
+        torch.cuda.synchronize()
+        assert list(timer.summary()) == ['fused_voice_bus[Sine,lp,gain]']
+        assert maxerr(got, f32(R.sum_bus(g[f'c2/{tag}']))) < 1e-7
+        assert maxerr(got, batched(c2_graph(g, bus=True), pos0, 256, 4, 1)) < 1e-7
+    rng = np.random.default_rng(13)
+    for V, N, K, C, kind, with_gain in ((3, 33, 5, 2, 'Square', True), (130, 100, 3, 1, 'Triangle', False),
+                                        (1024, 256, 3, 2, 'Sine', True), (200, 512, 2, 4, 'Sawtooth', True)):
+        hz, ph, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(200, 8000, (1, V))
+        gains = rng.uniform(-1, 1, (C, V)) / V if C > 1 else None
+
+        def build():
+            node = fx.HighPass(); node.input = mkosc(kind, hz, ph); node.cutoff = fix(cut)
+            if with_gain:
+                gn = fx.Gain(); gn.left = node; gn.right = fix(rng.uniform(0, 1, (1, V)) if False else np.full((1, V), 0.5))
+                node = gn
+            bus = ext.SumBus(); bus.input = node
+            if gains is not None:
+                bus.get_state().gains = gains
+            return bus
+        fused = batched(build(), 77, N, K, C, fuse=True)
+        plain = batched(build(), 77, N, K, C, fuse=False)
+        scale = max(1.0, float(np.abs(plain).max()))
+        assert fused.shape == (N * K, C) and maxerr(fused, plain) < 3e-7 * scale, (V, N, K, C, kind)
+    # reproducible bit for bit, run to run
+    a = batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True)
+    assert np.array_equal(a, batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True))

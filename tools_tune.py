@@ -81,3 +81,26 @@ if __name__ == '__main__' and os.environ.get('TUNE') == 'fused':
     for K in (256, 1024):
         ms = time_fused(K)
         print(f'fused vpt={os.environ.get("SIG_FUSED_VPT","default")} K={K}: {ms*1e3:.1f} us  {K*N*V/ms/1e3:.0f} Msamples/s', flush=True)
+
+
+def time_fused_bus(K, reps=20):
+    rng = np.random.default_rng(0)
+    mk = lambda lo, hi: torch.tensor(rng.uniform(lo, hi, (1, V)), device='cuda')
+    hz, ph, cut, g = mk(55, 1760), mk(0, 1), mk(200, 8000), mk(0, 1)
+    th = rng.uniform(0, np.pi / 2, V)
+    pan = torch.tensor(np.stack([np.cos(th), np.sin(th)]), device='cuda')
+    out = torch.empty((K * N, 2), device='cuda')
+    ws = torch.empty(_native.lib().sig_fused_voice_bus_workspace(V, K * N, 2) // 8, dtype=torch.float64, device='cuda')
+    f = lambda: _native.fused_voice_bus('Sine', 'lp', 48000, 0, N, K, 100, V, hz, ph, cut, g, pan, out, workspace=ws)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+if __name__ == '__main__' and os.environ.get('TUNE') == 'fusedbus':
+    for K in (256, 1024):
+        ms = time_fused_bus(K)
+        print(f'fused+bus vpt={os.environ.get("SIG_FUSED_VPT","default")} K={K}: {ms*1e3:.1f} us  {K*N*V/ms/1e3:.0f} Msamples/s', flush=True)
