@@ -1,0 +1,96 @@
+"""Full-size (BASELINE configs[1]: 1024 voices, 256-frame blocks, 256-block batches) checks through
+size-independent properties, plus spot checks against the CPU oracle on sampled voices/blocks
+(the oracle renders 1024 voices at ~3 blocks/s, so it cannot cover a whole batch)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from helpers import RATE, f32, maxerr
+
+pytestmark = pytest.mark.gpu
+V, N, K = 1024, 256, 256
+
+
+@pytest.fixture(scope='module')
+def params():
+    assert torch.cuda.is_available()
+    from signals_amd import runtime
+    runtime.set_device('cuda:0')
+    return bench.synth_params(V)
+
+
+def render(params, fuse, position=0, k=K, lo=0, hi=V, channels=2, gain_scale=None, node=None):
+    from signals_amd.engine import BatchRenderer
+    p = params if gain_scale is None else dict(params, gain=params['gain'] * gain_scale)
+    graph = bench.build_graph(p, lo, hi) if node is None else node
+    return BatchRenderer(graph, channels, RATE, fuse=fuse).render(position, N, k)
+
+
+def test_fused_and_materialised_schedules_agree(params):
+    a = render(params, True).cpu().numpy()
+    b = render(params, False).cpu().numpy()
+    assert a.shape == (N * K, 2) and np.isfinite(a).all()
+    assert maxerr(a, b) < 2e-7                       # bus values are O(0.03); each path is within 1e-7 of f64
+    assert float(np.abs(a).max()) > 1e-3             # not trivially zero
+
+
+def test_batching_is_invisible(params):
+    """one 256-block batch == 4 consecutive 64-block batches == a batch started mid-stream"""
+    whole = render(params, True)
+    from signals_amd.engine import BatchRenderer
+    r = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE)
+    parts = torch.cat([r.render(i * 64 * N, N, 64) for i in range(4)])
+    assert torch.equal(whole, parts)
+    tail = render(params, True, position=200 * N, k=56)
+    assert torch.equal(whole[200 * N:], tail)
+
+
+def test_bus_linearity_in_gain_and_voice_partition(params):
+    """the graph is linear in the per-voice gains and additive over voice ranges (what sharding relies on)"""
+    full = render(params, True, k=32).double()
+    doubled = render(params, True, k=32, gain_scale=2.0).double()
+    assert float((doubled - 2 * full).abs().max()) < 1e-7
+    halves = render(params, True, k=32, lo=0, hi=512).double() + render(params, True, k=32, lo=512, hi=V).double()
+    assert float((halves - full).abs().max()) < 1e-7
+
+
+def test_spot_check_against_oracle(params):
+    """8 sampled voices x blocks {0, 1, 137, 255}: per-voice Gain output vs the reference restatement"""
+    from oracle import chain_ref as R
+    from signals_amd.chain.fixed import Fixed
+    from signals_amd.chain.fx import Gain, LowPass
+    from signals_amd.chain.osc import Sine
+    from signals_amd.engine import BatchRenderer
+
+    def fixed(v):
+        f = Fixed(); f.get_state().value = np.ascontiguousarray(v); return f
+    o = Sine(); o.hertz = fixed(params['hertz']); o.phase = fixed(params['phase'])
+    lp = LowPass(); lp.input = o; lp.cutoff = fixed(params['cutoff'])
+    g = Gain(); g.left = lp; g.right = fixed(params['gain'])
+    voices = np.array([0, 1, 255, 256, 511, 700, 1022, 1023])
+    for fuse in (True, False):
+        got = BatchRenderer(g, V, RATE, fuse=fuse).render(0, N, K)
+        for b in (0, 1, 137, 255):
+            sub = {k: params[k][:, voices] for k in ('hertz', 'phase', 'cutoff', 'gain')}
+            ref = R.gain(R.filter_block('lp', lambda p, n: R.osc('Sine', p, n, RATE, sub['hertz'], sub['phase']),
+                                        b * N, N, RATE, sub['cutoff']), sub['gain'])
+            blk = got[b * N:(b + 1) * N][:, torch.from_numpy(voices).cuda()].cpu().numpy()
+            assert maxerr(blk, f32(ref)) < 1e-9, (fuse, b)          # gains are ~1/1024: 1e-6 relative to full scale
+
+
+def test_filter_output_is_bounded_and_blocks_are_cold_started(params):
+    """every block starts from zero state 100 frames early: shifting the stream by one block shifts the output"""
+    from signals_amd.chain.fixed import Fixed
+    from signals_amd.chain.fx import LowPass
+    from signals_amd.chain.osc import Sine
+    from signals_amd.engine import BatchRenderer
+
+    def fixed(v):
+        f = Fixed(); f.get_state().value = np.ascontiguousarray(v); return f
+    o = Sine(); o.hertz = fixed(params['hertz']); o.phase = fixed(params['phase'])
+    lp = LowPass(); lp.input = o; lp.cutoff = fixed(params['cutoff'])
+    a = BatchRenderer(lp, V, RATE).render(N, N, 64)             # blocks 1..64
+    b = BatchRenderer(lp, V, RATE).render(0, N, 65)[N:]         # same blocks inside a longer batch
+    assert torch.equal(a, b)
+    assert float(a.abs().max()) < 1.2                           # Butterworth overshoot only
