@@ -106,6 +106,101 @@ __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Span walker: one lane owns VPT voices x `span` CONSECUTIVE blocks and reads every input row ONCE.
+// The plain kernel re-reads each block's 100 context rows (they are the previous block's tail): measured
+// with rocprofv3 FETCH_SIZE the read side is 1.39x the algorithmic bytes at N=256 and none of it is
+// absorbed by L2 / Infinity Cache.  Here block m's warm-up (rows [(m+1)N-ctx, (m+1)N) of block m's main
+// region) runs as a SECOND chain on the same loaded row while block m's own chain is still producing
+// output; at the block boundary the warm chain becomes the output chain.  Arithmetic per chain is
+// unchanged (same zero start, same rows, same order), so results are bit-identical to the plain kernel.
+// Needs N > ctx (at most two live chains) and one cutoff row for all blocks.
+template <typename T, int VPT, int kRing>
+__global__ __launch_bounds__(256) void biquad_walk_kernel(
+    int type, double rate, int64_t position, int N, int K, int ctx, int voices, int span,
+    const double* __restrict__ cutoff, int cs,
+    const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld,
+    int voice_tiles, int* __restrict__ status)
+{
+    using Vec = typename RowVec<T, VPT>::type;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int vt = (int)(item % voice_tiles);
+    const int64_t b0 = (item / voice_tiles) * span;                           // first block of this lane's span
+    if (b0 >= K) return;                                                       // wave-uniform
+    const int nb = (K - b0 < span) ? (int)(K - b0) : span;                     // blocks in this span
+    const int v0 = (vt * SIG_WAVE + lane) * VPT;
+    const bool live = v0 < voices;
+    const int vc = live ? v0 : 0;
+
+    const int64_t p0 = position + b0 * N;
+    const int c0 = (int)((p0 < (int64_t)ctx) ? p0 : (int64_t)ctx);             // only the span's first block can be short
+
+    Biquad q[VPT];
+    double a0[VPT], a1[VPT], w0[VPT], w1[VPT];                                  // output chain / warm-up chain states
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int v = (vc + i < voices) ? vc + i : vc;
+        ok &= design_butter2(type, cutoff[(int64_t)v * cs], rate, q[i]);
+        a0[i] = a1[i] = w0[i] = w1[i] = 0.0;
+    }
+    if (!ok && live && status) atomicOr(status, SIG_STATUS_BAD_CUTOFF);
+
+    const int total = c0 + nb * N;
+    const T* src = in + (b0 * N - c0) * in_ld + vc;
+    T* dst = out + (b0 * N - c0) * out_ld + vc;
+
+    Vec ring[kRing];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) {
+        const int r = (u < total) ? u : total - 1;
+        ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)r * in_ld);
+    }
+
+    int in_block = -c0;                 // row index inside the current block; negative = the first block's own warm-up
+    int blocks_left = nb;
+    for (int r0 = 0; r0 < total; r0 += kRing) {
+#pragma unroll
+        for (int u = 0; u < kRing; ++u) {
+            const int r = r0 + u;
+            const bool valid = r < total;                                      // wave-uniform; tail rows are no-ops
+            double x[VPT], y[VPT];
+            unpack(ring[u], x);
+            const int rn = (r + kRing < total) ? r + kRing : total - 1;
+            ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * in_ld);
+            const bool warm = valid && (blocks_left > 1) && (in_block >= N - ctx);   // next block's context rows
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    y[i] = q[i].b0 * x[i] + a0[i];
+                    a0[i] = q[i].b1 * x[i] - q[i].a1 * y[i] + a1[i];
+                    a1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
+                }
+            }
+            if (warm) {
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const double yw = q[i].b0 * x[i] + w0[i];
+                    w0[i] = q[i].b1 * x[i] - q[i].a1 * yw + w1[i];
+                    w1[i] = q[i].b2 * x[i] - q[i].a2 * yw;
+                }
+            }
+            if (valid && in_block >= 0 && live) {
+                Vec o; pack(o, y);
+                *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
+            }
+            in_block += valid ? 1 : 0;
+            if (in_block == N) {                                                // block boundary: warm chain takes over
+                in_block = 0;
+                --blocks_left;
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) { a0[i] = w0[i]; a1[i] = w1[i]; w0[i] = 0.0; w1[i] = 0.0; }
+            }
+        }
+    }
+}
+
 static int biquad_variant() {
     // tuning hook: SIG_BIQUAD_VARIANT=<vpt><ring> e.g. "416" = 4 voices/lane, 16-row ring
     static int v = [] { const char* e = getenv("SIG_BIQUAD_VARIANT"); return e ? atoi(e) : 0; }();
@@ -123,6 +218,27 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
                (reinterpret_cast<uintptr_t>(out) % (vpt * sizeof(T)) == 0);
     };
     int variant = biquad_variant();
+    // span walker: every row read once (see biquad_walk_kernel).  Keep >= ~2048 waves on the chip.
+    {
+        static const int walk_env = [] { const char* e = getenv("SIG_BIQUAD_WALK"); return e ? atoi(e) : -1; }();
+        const int wvpt = ok(2) ? 2 : 1;
+        const int tiles = (voices + SIG_WAVE * wvpt - 1) / (SIG_WAVE * wvpt);
+        int span = (int)(((int64_t)tiles * K) / 2048);
+        if (span > 8) span = 8;
+        if (walk_env >= 0) span = walk_env;                                    // tuning: 0/1 disables
+        if (span >= 2 && N > ctx && cutoff_blocks == 1 && variant == 0) {
+            const int64_t items = (int64_t)tiles * ((K + span - 1) / span);
+            const int64_t nwg = (items + 3) / 4;
+            if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+            if (wvpt == 2)
+                biquad_walk_kernel<T, 2, 16><<<(unsigned)nwg, 256, 0, stream>>>(
+                    type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status);
+            else
+                biquad_walk_kernel<T, 1, 16><<<(unsigned)nwg, 256, 0, stream>>>(
+                    type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status);
+            return sig_launch_status();
+        }
+    }
     int vpt = variant ? variant / 100 : 4;
     int ring = variant ? variant % 100 : 8;
     if (!ok(vpt)) { vpt = 1; ring = 8; }

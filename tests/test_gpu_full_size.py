@@ -94,3 +94,25 @@ def test_filter_output_is_bounded_and_blocks_are_cold_started(params):
     b = BatchRenderer(lp, V, RATE).render(0, N, 65)[N:]         # same blocks inside a longer batch
     assert torch.equal(a, b)
     assert float(a.abs().max()) < 1.2                           # Butterworth overshoot only
+
+
+def test_span_walker_is_bit_identical_to_the_plain_biquad_kernel(params):
+    """K=512 x 1024 voices makes sig_biquad_coldstart pick the span walker (every input row read once, two
+    live chains); 64-block batches use the plain kernel.  Same chains, same order: bitwise equal."""
+    from signals_amd.chain.fixed import Fixed
+    from signals_amd.chain.fx import HighPass
+    from signals_amd.chain.osc import Sawtooth
+    from signals_amd.engine import BatchRenderer
+
+    def fixed(v):
+        f = Fixed(); f.get_state().value = np.ascontiguousarray(v); return f
+
+    def build():
+        o = Sawtooth(); o.hertz = fixed(params['hertz']); o.phase = fixed(params['phase'])
+        hp = HighPass(); hp.input = o; hp.cutoff = fixed(params['cutoff'])
+        return hp
+    for pos in (0, 37):                                   # 37: the first block's context is short (c = 37)
+        whole = BatchRenderer(build(), V, RATE, fuse=False).render(pos, N, 512)
+        r = BatchRenderer(build(), V, RATE, fuse=False)
+        parts = torch.cat([r.render(pos + i * 64 * N, N, 64) for i in range(8)])
+        assert torch.equal(whole, parts), pos

@@ -104,3 +104,8 @@ if __name__ == '__main__' and os.environ.get('TUNE') == 'fusedbus':
     for K in (256, 1024):
         ms = time_fused_bus(K)
         print(f'fused+bus vpt={os.environ.get("SIG_FUSED_VPT","default")} K={K}: {ms*1e3:.1f} us  {K*N*V/ms/1e3:.0f} Msamples/s', flush=True)
+
+if __name__ == '__main__' and os.environ.get('TUNE') == 'walk':
+    for K in (256, 1024):
+        ms, gbs = time_biquad(K)
+        print(f'walk={os.environ.get("SIG_BIQUAD_WALK","auto")} K={K}: {ms*1e3:.1f} us  {gbs:.0f} GB/s algorithmic', flush=True)
