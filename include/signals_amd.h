@@ -36,7 +36,7 @@ enum { SIG_F32 = 0, SIG_F64 = 1 };
 enum { SIG_OSC_SINE = 0, SIG_OSC_SQUARE = 1, SIG_OSC_SAWTOOTH = 2, SIG_OSC_TRIANGLE = 3 };
 
 /* critical-frequency filter types: fx.py:68-72 (only lp/hp are live in the reference, fx.py:142-151) */
-enum { SIG_FILT_LOWPASS = 0, SIG_FILT_HIGHPASS = 1 };
+enum { SIG_FILT_LOWPASS = 0, SIG_FILT_HIGHPASS = 1, SIG_FILT_BANDPASS = 2, SIG_FILT_BANDSTOP = 3 };
 
 /* element-wise effects: fx.py:35-60 */
 enum { SIG_EW_GAIN = 0, SIG_EW_MIX = 1, SIG_EW_RINGMOD = 2, SIG_EW_AMP = 3 };
@@ -74,6 +74,18 @@ int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
                          const void* in, int64_t in_ld, int64_t in_history,
                          void* out, int64_t out_ld, int32_t dtype,
                          int32_t* status, void* stream);
+
+/* BandPass / BandStop done right (the reference's DoubleCritFilter raises TypeError at
+ * fx.py:99, its intent being butter(N=2, Wn=[low, high], btype='bp'|'bs', output='sos') + sosfilt):
+ * two biquad sections in series, designed in closed form per voice, same cold-start block semantics and
+ * buffer conventions as sig_biquad_coldstart.  low/high: f64 rows (1,V)|(1,1).
+ * Pinned against scipy.signal.butter + sosfilt (the reference itself has no working output to compare). */
+int sig_band_coldstart(int type, int32_t rate, int64_t position,
+                       int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                       const double* low, int32_t low_stride, const double* high, int32_t high_stride,
+                       const void* in, int64_t in_ld, int64_t in_history,
+                       void* out, int64_t out_ld, int32_t dtype,
+                       int32_t* status, void* stream);
 
 /* One operand of an element-wise effect.  row_stride / col_stride are in elements; 0 broadcasts
  * that axis (numpy broadcasting of (1,V), (N,1), (1,1) replies). */

@@ -140,6 +140,71 @@ def crit_filter(btype: str, window: np.ndarray, cutoff: np.ndarray, rate: int, f
     return result
 
 
+def band2_sos(wn_lo: float, wn_hi: float, btype: str) -> np.ndarray:
+    """Closed form of scipy.signal.butter(2, [wn_lo, wn_hi], 'bp'|'bs', output='sos') -- two sections.
+    Restates buttap -> lp2bp_zpk / lp2bs_zpk -> bilinear_zpk (fs = 2) -> zpk2sos ('nearest' pairing: the
+    pole pair closest to the unit circle goes last and takes the nearest zeros; gain on the first section).
+    This is the arithmetic signals_amd/csrc/sig_biquad.h:design_band2 runs on the GPU."""
+    if not (0.0 < wn_lo < 1.0 and 0.0 < wn_hi < 1.0):
+        raise ValueError('Digital filter critical frequencies must be 0 < Wn < 1')
+    if wn_lo >= wn_hi:
+        raise ValueError('Wn[0] must be less than Wn[1]')
+
+    def csqrt(z: complex) -> complex:
+        m = math.hypot(z.real, z.imag)
+        if m == 0:
+            return 0j
+        if z.real >= 0:
+            t = math.sqrt((m + z.real) / 2)
+            return complex(t, z.imag / (2 * t))
+        t = math.sqrt((m - z.real) / 2)
+        return complex(abs(z.imag) / (2 * t), math.copysign(t, z.imag))
+
+    w1, w2 = 4 * math.tan(math.pi * wn_lo / 2), 4 * math.tan(math.pi * wn_hi / 2)
+    bw, wo2 = w2 - w1, w1 * w2
+    p = complex(-math.sqrt(0.5), math.sqrt(0.5))
+    c = p * bw / 2 if btype == 'bp' else (bw / 2) / p
+    s = csqrt(c * c - wo2)
+    qa, qb = c + s, c - s
+    poles = []
+    for q in (qa, qb):
+        P = (4 + q) / (4 - q)
+        poles.append(P if P.imag >= 0 else P.conjugate())
+    den = abs(4 - qa) ** 2 * abs(4 - qb) ** 2
+    a_worst = abs(1 - abs(poles[0])) <= abs(1 - abs(poles[1]))
+    worst, other = (poles[0], poles[1]) if a_worst else (poles[1], poles[0])
+    if btype == 'bp':
+        kz = bw * bw * 16.0 / den
+        z1 = 1.0 if abs(worst - 1) <= abs(worst + 1) else -1.0
+        b_last, b_first = [1.0, -2 * z1, 1.0], [1.0, 2 * z1, 1.0]
+    elif btype == 'bs':
+        z0 = complex(4, math.sqrt(wo2)) / complex(4, -math.sqrt(wo2))
+        kz = (16.0 + wo2) ** 2 / den
+        b_last = b_first = [1.0, -2 * z0.real, 1.0]
+    else:
+        raise ValueError(btype)
+
+    def a_of(P):
+        return [1.0, -2 * P.real, P.real ** 2 + P.imag ** 2]
+    return np.array([[kz * v for v in b_first] + a_of(other), b_last + a_of(worst)])
+
+
+def band_filter(btype: str, window: np.ndarray, low: np.ndarray, high: np.ndarray, rate: int, frames: int,
+                ctx: int = CONTEXT_FRAMES, *, closed_form: bool = False) -> np.ndarray:
+    """BandPass/BandStop as the reference INTENDS them (fx.py:85-106 with crit_2; the shipped code raises
+    TypeError at :99): per channel butter(N=2, Wn=[low, high]/(rate/2), btype) -> 2 sections, sosfilt over the
+    window from zero state, keep `[-(frames+ctx):-ctx]`.  Parity unpinned by the reference; pinned to scipy."""
+    result = np.empty((frames, window.shape[1]))
+    for i in range(window.shape[1]):
+        wn = np.array([low[0, i], high[0, i]], dtype=float)
+        wn /= rate / 2
+        wn.clip(0, 1, out=wn)
+        sos = band2_sos(float(wn[0]), float(wn[1]), btype) if closed_form else \
+            scipy.signal.butter(N=2, Wn=wn, btype=btype, output='sos')
+        result[:, i] = scipy.signal.sosfilt(sos, window[:, i], axis=0)[-(frames + ctx):-ctx]
+    return result
+
+
 def filter_block(btype: str, source, position: int, frames: int, rate: int, cutoff: np.ndarray,
                  ctx: int = CONTEXT_FRAMES, **kw) -> np.ndarray:
     """Single filter over a position-pure `source(position, frames) -> array`
@@ -313,6 +378,18 @@ class Filter(Node):
         if window.shape[1] != channels:
             raise IndexError('filter input narrower than the request (fx.py:98-105)')
         return crit_filter(self.btype, window, cutoff, rate, frames, **self.kw)
+
+
+class BandFilter(Node):
+    def __init__(self, btype, input=None, low=None, high=None):
+        super().__init__(input=input, low=low, high=high)
+        self.btype = btype
+
+    def eval(self, position, frames, channels, rate):
+        low = self._ctrl('low', position, channels, rate)
+        high = self._ctrl('high', position, channels, rate)
+        window = self._with_context('input', position, frames, channels, rate, CONTEXT_FRAMES)
+        return band_filter(self.btype, window, low, high, rate, frames)
 
 
 class Binary(Node):

@@ -14,13 +14,13 @@ LIB_PATH = pathlib.Path(__file__).resolve().parent / 'csrc' / 'libsignals_amd.so
 
 F32, F64 = 0, 1
 OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
-FILT_TYPES = {'lp': 0, 'hp': 1}
+FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
-           'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace')
+           'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart')
 
 
 class NativeError(RuntimeError):
@@ -70,6 +70,9 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus.restype = ctypes.c_int
         L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                           dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_band_coldstart.restype = ctypes.c_int
+        L.sig_band_coldstart.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, dp, i32,
+                                         vp, i64, i64, vp, i64, i32, vp, vp]
         if L.sig_abi_version() != 1:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -286,4 +289,27 @@ def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frame
                                      voices, *ptrs, gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
                                      status.data_ptr() if status is not None else None, _stream(out)),
            'sig_fused_voice_bus')
+    return out
+
+
+def band_coldstart(btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                   low: torch.Tensor, high: torch.Tensor, buf: torch.Tensor, history: int, out: torch.Tensor,
+                   status: torch.Tensor | None = None) -> torch.Tensor:
+    """BandPass ('bp') / BandStop ('bs'): two biquad sections; buffers as in `biquad_coldstart`."""
+    _gpu(low, high, buf, out, status)
+    _audio(buf, 'band in')
+    _audio(out, 'band out')
+    rows, voices = out.shape
+    if rows != block_frames * nblocks or buf.shape[0] != history + rows or buf.shape[1] != voices or buf.dtype != out.dtype:
+        raise NativeError(f'band shapes: in {tuple(buf.shape)} history {history} out {tuple(out.shape)}')
+    ptrs = []
+    for row, name in ((low, 'low'), (high, 'high')):
+        if row.shape[1] != voices and voices != 1:
+            raise IndexError(f'index {row.shape[1]} is out of bounds for axis 1 with size {row.shape[1]}')
+        ptrs.extend(_ctrl_row(row, name))
+    in_ptr = buf.data_ptr() + history * buf.stride(0) * buf.element_size()
+    _check(lib().sig_band_coldstart(FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices, *ptrs,
+                                    in_ptr, buf.stride(0), history, out.data_ptr(), out.stride(0), _dt(out),
+                                    status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_band_coldstart')
     return out

@@ -109,8 +109,7 @@ class CritFilter(Effect, abc.ABC):
     def _filter(self, request: Request, crit_1: torch.Tensor, crit_2: torch.Tensor = None) -> torch.Tensor:
         assert Shape.of_array(crit_1).frames == 1
         if crit_2 is not None:
-            # the reference unpacks a scalar here and raises for every band filter (fx.py:99)
-            raise TypeError('Value after * must be an iterable, not numpy.float64')
+            assert Shape.of_array(crit_2).frames == 1
         context_frames = self.context_frames()
         window = self.input.forward_with_context(request, context_frames)
         shape = request.loc.shape
@@ -132,6 +131,18 @@ class CritFilter(Effect, abc.ABC):
         if self._status is None:
             self._status = runtime.StatusWord(self.cls_name())
         result = torch.empty(tuple(shape), dtype=dtype, device=buf.device)
+        if crit_2 is not None:
+            # The reference raises TypeError here for every band filter (it star-unpacks a scalar, fx.py:99).
+            # Its evident intent -- butter(N=2, Wn=[low, high], 'bp'|'bs') + sosfilt over the same window --
+            # is what runs instead, pinned against scipy.
+            if crit_2.shape[1] < shape.channels:
+                raise IndexError(f'index {crit_2.shape[1]} is out of bounds for axis 1 with size {crit_2.shape[1]}')
+            high = crit_2[:, :shape.channels]
+            if not high.is_contiguous():
+                high = high.contiguous()
+            return _native.band_coldstart(str(self.type()), request.loc.rate, request.loc.position, shape.frames, 1,
+                                          context_frames, cutoff, high, buf, history, result,
+                                          status=self._status.tensor)
         return _native.biquad_coldstart(str(self.type()), request.loc.rate, request.loc.position,
                                         shape.frames, 1, context_frames, cutoff, buf, history, result,
                                         status=self._status.tensor)
@@ -168,14 +179,16 @@ class HighPass(SingleCritFilter):
 
 
 class BandPass(DoubleCritFilter):
-    """Raises TypeError on every block, exactly like the reference; a working
-    two-section band filter is SURVEY.md §8f-4."""
+    """4th-order Butterworth band-pass between the `low` and `high` ports (two biquad sections).  The
+    reference class raises TypeError on every block (fx.py:99); this is its intent,
+    `butter(2, [low, high], 'bp', output='sos')` + `sosfilt`, per SURVEY.md §8f-4."""
 
     def type(self) -> CritFilter.Type:
         return self.Type.band_pass
 
 
 class BandStop(DoubleCritFilter):
+    """4th-order Butterworth band-stop; see `BandPass`."""
 
     def type(self) -> CritFilter.Type:
         return self.Type.band_stop

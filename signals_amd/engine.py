@@ -236,11 +236,8 @@ class _Batch:
             seed, start = node.get_state().seed, self.pos - hist
             o._launch('white_noise', lambda: _native.white_noise(seed, start, result), units=rows * channels)
 
-        elif isinstance(node, fx.SingleCritFilter):
-            result = self._filter(node, channels, hist, rows)
-
         elif isinstance(node, fx.CritFilter):
-            raise TypeError('Value after * must be an iterable, not numpy.float64')     # fx.py:99, like eager
+            result = self._filter(node, channels, hist, rows)
 
         elif isinstance(node, (fx.Mix, fx.RingMod, fx.Gain, fx.Amp)):
             a = self._operand(node.left, channels, hist)
@@ -374,10 +371,12 @@ class _Batch:
         return result
 
     # -------------------------------------------------------------- filters
-    def _filter(self, node: fx.SingleCritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:
+    def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:
         o = self.owner
         N, K, pos = self.N, self.K, self.pos
-        cutoff = self._control(node.cutoff, 'cutoff')
+        band = isinstance(node, fx.DoubleCritFilter)
+        cutoff = self._control(node.low if band else node.cutoff, 'low' if band else 'cutoff')
+        high = self._control(node.high, 'high') if band else None
         c0 = min(CONTEXT, pos)
         src = node.input.sig
         pure_in = _is_pure(src, self._pure)
@@ -399,10 +398,21 @@ class _Batch:
         main = result[hist:]
         btype = str(node.type())
         status = o._status_word(node)
-        o._launch(f'biquad_coldstart[{btype}]',
-                  lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
-                                                   status=status),
-                  units=N * K * channels)
+        if band:
+            if high.shape[1] < channels:
+                raise IndexError(f'index {high.shape[1]} is out of bounds for axis 1 with size {high.shape[1]}')
+            high = high[:, :channels]
+            if not high.is_contiguous():
+                high = high.contiguous()
+            o._launch(f'band_coldstart[{btype}]',
+                      lambda: _native.band_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, high, window, c0, main,
+                                                     status=status),
+                      units=N * K * channels)
+        else:
+            o._launch(f'biquad_coldstart[{btype}]',
+                      lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
+                                                       status=status),
+                      units=N * K * channels)
         if hist:
             # this filter's own history rows: the previous batch's tail, or a fresh block [pos-hist, pos)
             tail = o._tails.get(node) if self.continuing else None

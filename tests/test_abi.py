@@ -21,7 +21,7 @@ def lib():
 def declared_symbols():
     text = (ROOT / 'include' / 'signals_amd.h').read_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\bint\s+(sig_\w+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(?:int|int64_t)\s+(sig_\w+)\s*\(', text)))
 
 
 def test_header_and_binding_agree():

@@ -208,6 +208,32 @@ def test_bad_cutoff_raises_like_scipy():
     f = fx.LowPass(); f.input = mkosc('Sine', [[440.0, 220.0]]); f.cutoff = fix([[1000.0]])
     with pytest.raises(IndexError):
         render(f, 0, 64, 2)
-    bp = fx.BandPass(); bp.input = mkosc('Sine', [[440.0]]); bp.low = fix([[100.0]]); bp.high = fix([[1000.0]])
-    with pytest.raises(TypeError):
-        render(bp, 0, 64, 1)
+    bp = fx.BandPass(); bp.input = mkosc('Sine', [[440.0, 440.0]]); bp.low = fix([[1000.0, 100.0]]); bp.high = fix([[100.0, 1000.0]])
+    out = render(bp, 0, 64, 2)          # voice 0: low >= high -> scipy's ValueError, surfaced at the sink edge
+    assert np.isnan(out[:, 0]).all() and np.isfinite(out[:, 1]).all()
+    with pytest.raises(ValueError):
+        runtime.check_status()
+
+
+@pytest.mark.parametrize('cls,btype', (('BandPass', 'bp'), ('BandStop', 'bs')))
+def test_band_filters_vs_scipy(cls, btype):
+    """the reference's band filters crash; pinned against scipy butter(2,[lo,hi]) + sosfilt"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import fx
+    from helpers import stream
+    rng = np.random.default_rng(17)
+    V = 16
+    hz, ph = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V))
+    lo = np.geomspace(40, 6000, V).reshape(1, V)
+    hi = lo * rng.uniform(1.2, 4.0, (1, V))
+
+    def build():
+        f = getattr(fx, cls)(); f.input = mkosc('Sawtooth', hz, ph); f.low = fix(lo); f.high = fix(hi)
+        return f
+    for pos, n in ((0, 256), (50, 100), (HOUR, 512)):
+        got = render(build(), pos, n, V)
+        ref = R.render(R.BandFilter(btype, R.Osc('Sawtooth', R.Fixed(hz), R.Fixed(ph)), R.Fixed(lo), R.Fixed(hi)), pos, n, V)
+        assert maxerr(got, f32(ref)) < 5e-7, (cls, pos, n)
+    from signals_amd.engine import BatchRenderer
+    batch = BatchRenderer(build(), V, RATE).render(0, 256, 4).cpu().numpy()
+    assert np.array_equal(batch, stream(build(), 0, 256, 4, V))

@@ -36,3 +36,24 @@ def test_adsr_shape_of_envelope():
     # zero-length stages count as complete
     z = dict(rows, attack=[[0.0]], decay=[[0.0]])
     assert R.adsr(0, 24000, 48000, **z)[np.searchsorted(t, 0.1001), 0] == 0.5
+
+
+def test_band_closed_form_matches_scipy():
+    """the arithmetic design_band2 runs on the GPU, restated in Python, against scipy.signal.butter"""
+    import scipy.signal
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for btype in ('bp', 'bs'):
+        for _ in range(1500):
+            lo = rng.uniform(20, 20000)
+            hi = rng.uniform(lo * 1.001, 23900)
+            ref = scipy.signal.butter(2, [lo / 24000, hi / 24000], btype, output='sos')
+            got = R.band2_sos(lo / 24000, hi / 24000, btype)
+            assert got.shape == ref.shape == (2, 6)
+            worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))))
+    assert worst < 1e-11, worst
+    import pytest
+    with pytest.raises(ValueError):
+        R.band2_sos(0.5, 0.25, 'bp')
+    with pytest.raises(ValueError):
+        R.band2_sos(0.0, 0.25, 'bs')
