@@ -42,7 +42,7 @@ def install_as_signals() -> None:
     """Make `import signals.chain.osc` (and friends) resolve to this package."""
     import importlib
     names = ['', '.discovery', '.chain', '.chain.osc', '.chain.fx', '.chain.fixed', '.chain.noise',
-             '.chain.shape', '.chain.ext', '.chain.driver']
+             '.chain.shape', '.chain.ext', '.chain.files', '.chain.driver', '.chain.sigs']
     for suffix in names:
         mod = importlib.import_module(__name__ + suffix)
         sys.modules['signals' + suffix] = mod

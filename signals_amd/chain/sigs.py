@@ -8,8 +8,8 @@ map/__init__.py:104-148; coordinates :54-101), enough to load its two fixture pa
     > 1a 2a.hertz                                     -> node at 2a: .hertz = node at 1a
 
 Editing, undo/redo and the GUI are out of scope.  Node classes that only exist
-for devices, files and plots (`signals.chain.vis.*`, `signals.chain.files.*`) load as `Tap`, a
-pass-through that keeps the topology intact.
+for plots (`signals.chain.vis.*`) load as `Tap`, a pass-through that keeps the topology intact;
+`signals.chain.files.FileWriter/FileReader` resolve to the WAV taps in `signals_amd.chain.files`.
 """
 from __future__ import annotations
 
@@ -28,7 +28,7 @@ from signals_amd.chain.ext import Tap
 from signals_amd.chain.driver import BlockDriver, load_signal
 
 _COORD = re.compile(r'(\d+)([a-z]+)')
-_TAP_MODULES = ('signals.chain.vis', 'signals.chain.files')
+_TAP_MODULES = ('signals.chain.vis',)
 
 
 class PatchError(SignalsError):

@@ -35,7 +35,7 @@ from signals_amd.chain import (
     as_control,
     broadcast_shape,
 )
-from signals_amd.chain import ext, fixed, fx, noise, osc, shape
+from signals_amd.chain import ext, files, fixed, fx, noise, osc, shape
 
 CONTEXT = 100
 
@@ -170,7 +170,7 @@ class _Batch:
         if self._need.get(key, -1) >= hist:
             return
         self._need[key] = hist
-        if not node.get_state().enabled and not isinstance(node, ext.Tap):
+        if not node.get_state().enabled and not isinstance(node, (ext.Tap, files.FileWriter)):
             return
         if isinstance(node, fx.CritFilter):
             self._require(node.input.sig, channels, min(CONTEXT, self.pos))
@@ -181,7 +181,7 @@ class _Batch:
             self._require(node.left.sig, channels, hist)
         elif isinstance(node, ext.SumBus):
             self._require(node.input.sig, node.input.channels, hist)
-        elif isinstance(node, (ext.MixMatrix, ext.Tap)):
+        elif isinstance(node, (ext.MixMatrix, ext.Tap, files.FileWriter)):
             self._require(node.input.sig, channels, hist)
         elif isinstance(node, shape.Merge):
             self._require(node.left.sig, node.left.channels, hist)
@@ -203,7 +203,7 @@ class _Batch:
         rows = hist + self.N * self.K
         dev = runtime.device()
         o = self.owner
-        if node is not None and isinstance(node, ext.Tap) and not node.get_state().enabled:
+        if node is not None and isinstance(node, (ext.Tap, files.FileWriter)) and not node.get_state().enabled:
             self._memo[key] = self._materialise(node.input.sig, channels)      # PASSTHRU: disabled = forward input
             return self._memo[key]
         if node is None or not node.get_state().enabled:
@@ -267,6 +267,18 @@ class _Batch:
         elif isinstance(node, ext.Tap):
             self._memo[key] = self._materialise(node.input.sig, channels)      # pass-through: same buffer
             return self._memo[key]
+
+        elif isinstance(node, files.FileWriter):
+            full, have = self._materialise(node.input.sig, channels)           # pass-through + record the batch
+            if full.shape[0] > 1:
+                node.write_rows(self.pos, self.rate, channels, full[have:])
+            self._memo[key] = (full, have)
+            return self._memo[key]
+
+        elif isinstance(node, files.FileReader):
+            result = node.read_rows(self.pos - hist, rows, self.rate, channels)
+            if result.shape[0] != rows:
+                raise NotBatchable('FileReader ran past the end of the file inside a batch')
 
         elif isinstance(node, ext.ADSR):
             ctl = node.control_rows(lambda bound: self._control(bound, bound.name))

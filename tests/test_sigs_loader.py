@@ -44,7 +44,8 @@ def test_lowpass_test_patch_topology():
     assert isinstance(merge, shape.Merge) and merge.left.sig is lp and merge.right.sig is gain and merge.channels == 2
     assert lp.input.sig is gain and lp.cutoff.sig is p['1c'] and gain.left.sig is tri and gain.right.sig is p['1b']
     assert p['7a'].input.sig is p['6a'] and p['6a'].input.sig is p['5c'] and p['5c'].input.sig is lp
-    assert p['5c'].original_state['path'] == '/tmp/lowpass_test.wav'
+    from signals_amd.chain.files import FileWriter
+    assert isinstance(p['5c'], FileWriter) and p['5c'].get_state().path == '/tmp/lowpass_test.wav'
 
 
 def test_loader_errors():
@@ -83,3 +84,51 @@ def test_example_sine_script():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(['500', '-a', '0.2', '-n', '4']) < 1e-6
+
+
+def test_wave_file_roundtrip_on_host(tmp_path):
+    """the WAV container itself (no GPU): PCM_16 quantisation, FLOAT lossless, positional writes"""
+    import wave
+    from signals_amd.chain.files import _WaveFile
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (1000, 2))
+    for subtype, tol in (('PCM_16', 5e-5), ('FLOAT', 1e-7)):      # write x32767, read /32768 (libsndfile's convention)
+        path = tmp_path / f'{subtype}.wav'
+        f = _WaveFile(path, 'w', 48000, 2, subtype)
+        f.write(500, x[500:])                      # out of order: tail first (gap is silence)
+        f.write(0, x[:500])
+        f.close()
+        r = _WaveFile(path, 'r')
+        assert (r.samplerate, r.channels, r.frames, r.subtype) == (48000, 2, 1000, subtype)
+        assert np.max(np.abs(r.read(0, 1000) - x)) <= tol
+        assert r.read(900, 256).shape == (100, 2)  # short read at the end
+        r.close()
+    with wave.open(str(tmp_path / 'PCM_16.wav')) as w:      # a standard reader agrees with the header
+        assert (w.getnchannels(), w.getframerate(), w.getnframes(), w.getsampwidth()) == (2, 48000, 1000, 2)
+
+
+@pytest.mark.gpu
+def test_file_taps_on_gpu(tmp_path, golden):
+    from signals_amd import runtime
+    runtime.set_device('cuda:0')
+    from signals_amd.chain.files import FileReader, FileWriter
+    from helpers import mkosc, stream
+    g = golden('c2')
+    path = tmp_path / 'take.wav'
+    w = FileWriter(); w.get_state().path = str(path); w.get_state().subtype = 'FLOAT'
+    w.input = mkosc('Sine', g['c2/hertz'][:, :2], g['c2/phase'][:, :2])
+    d = BlockDriver(); d.get_state().channels = 2; d.input = w
+    batched = d.render(4)                                   # engine path: one write of 1024 rows
+    w.destroy()
+    r = FileReader(); r.get_state().path = str(path)
+    back = stream(r, 0, 256, 4, 2)                          # eager path: 4 positional reads
+    assert np.array_equal(back, batched)
+    d2 = BlockDriver(); d2.get_state().channels = 2; d2.input = r
+    assert np.array_equal(d2.render(4), batched)            # and the batched reader
+    w2 = FileWriter(); w2.get_state().path = str(tmp_path / 'pcm.wav')
+    w2.input = mkosc('Sine', g['c2/hertz'][:, :2], g['c2/phase'][:, :2])
+    eager = stream(w2, 0, 256, 4, 2)                        # pass-through result is the input, untouched
+    assert np.array_equal(eager, batched)
+    w2.destroy()
+    r2 = FileReader(); r2.get_state().path = str(tmp_path / 'pcm.wav')
+    assert np.max(np.abs(stream(r2, 0, 256, 4, 2) - batched)) < 5e-5      # 16-bit quantisation
