@@ -32,6 +32,8 @@ __device__ __forceinline__ void put(float& v, const float (&y)[1]) { v = y[0]; }
 __device__ __forceinline__ void put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
 __device__ __forceinline__ void put(float4& v, const float (&y)[4]) { v = make_float4(y[0], y[1], y[2], y[3]); }
 
+constexpr int kIlp = 4;     // rows whose oscillator samples are computed ahead of the recurrence
+
 struct FusedArgs {
     int type; double rate; int64_t position; int N, K, ctx, voices;
     const double* hertz; int hs; const double* phase; int ps;
@@ -79,24 +81,41 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
         for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
             const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
             const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
-            for (int j = 0; j < lim; ++j) {
-                const double t_s = sig_readlane_f64(q_lane, j);
-                float y32[VPT];
+            // oscillator samples of kIlp rows are independent of the filter state: compute them first so their
+            // long dependent chains overlap, then run the (serial) recurrence over them
+            auto rows = [&](int j, auto count_tag) {
+                constexpr int CNT = decltype(count_tag)::value;
+                double xs[CNT][VPT];
 #pragma unroll
-                for (int i = 0; i < VPT; ++i) {
-                    const double t = t_s * hz[i] + ph[i];
-                    const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                            : sig_osc::osc_wave<KIND, double>(t);
-                    const double y = q[i].b0 * x + z0[i];                     // scipy _sosfilt order, contract off
-                    z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
-                    z1[i] = q[i].b2 * x - q[i].a2 * y;
-                    if (STORE) y32[i] = (float)(GAIN ? y * g[i] : y);
+                for (int u = 0; u < CNT; ++u) {
+                    const double t_s = sig_readlane_f64(q_lane, j + u);
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) {
+                        const double t = t_s * hz[i] + ph[i];
+                        xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                           : sig_osc::osc_wave<KIND, double>(t);
+                    }
                 }
-                if (STORE && live) {
-                    Vec o; put(o, y32);
-                    *reinterpret_cast<Vec*>(dst + (int64_t)(r0 + j) * a.out_ld) = o;
+#pragma unroll
+                for (int u = 0; u < CNT; ++u) {
+                    float y32[VPT];
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) {
+                        const double x = xs[u][i];
+                        const double y = q[i].b0 * x + z0[i];                 // scipy _sosfilt order, contract off
+                        z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
+                        z1[i] = q[i].b2 * x - q[i].a2 * y;
+                        if (STORE) y32[i] = (float)(GAIN ? y * g[i] : y);
+                    }
+                    if (STORE && live) {
+                        Vec o; put(o, y32);
+                        *reinterpret_cast<Vec*>(dst + (int64_t)(r0 + j + u) * a.out_ld) = o;
+                    }
                 }
-            }
+            };
+            int j = 0;
+            for (; j + kIlp <= lim; j += kIlp) rows(j, std::integral_constant<int, kIlp>{});
+            for (; j < lim; ++j) rows(j, std::integral_constant<int, 1>{});
         }
     };
     walk(0, c, std::false_type{});
@@ -174,30 +193,45 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
         for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
             const double q_lane = (double)(n0 + r0 + lane) / a.rate;
             const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
-            for (int j = 0; j < lim; ++j) {
-                const double t_s = sig_readlane_f64(q_lane, j);
-                double acc[C];
+            auto rows = [&](int j, auto count_tag) {
+                constexpr int CNT = decltype(count_tag)::value;
+                double xs[CNT][VPT];
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0;
+                for (int u = 0; u < CNT; ++u) {
+                    const double t_s = sig_readlane_f64(q_lane, j + u);
 #pragma unroll
-                for (int i = 0; i < VPT; ++i) {
-                    const double t = t_s * hz[i] + ph[i];
-                    const double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                            : sig_osc::osc_wave<KIND, double>(t);
-                    const double y = q[i].b0 * x + z0[i];
-                    z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
-                    z1[i] = q[i].b2 * x - q[i].a2 * y;
-                    if (STORE) {
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) acc[ch] = fma(w[ch][i], y, acc[ch]);
+                    for (int i = 0; i < VPT; ++i) {
+                        const double t = t_s * hz[i] + ph[i];
+                        xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                           : sig_osc::osc_wave<KIND, double>(t);
                     }
                 }
-                if (STORE) {
 #pragma unroll
-                    for (int ch = 0; ch < C; ++ch) tile[(staged * C + ch) * kTileStride + lane] = acc[ch];
-                    if (++staged == R) { flush(first, R); first += R; staged = 0; }
+                for (int u = 0; u < CNT; ++u) {
+                    double acc[C];
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) {
+                        const double x = xs[u][i];
+                        const double y = q[i].b0 * x + z0[i];
+                        z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
+                        z1[i] = q[i].b2 * x - q[i].a2 * y;
+                        if (STORE) {
+#pragma unroll
+                            for (int ch = 0; ch < C; ++ch) acc[ch] = fma(w[ch][i], y, acc[ch]);
+                        }
+                    }
+                    if (STORE) {
+#pragma unroll
+                        for (int ch = 0; ch < C; ++ch) tile[(staged * C + ch) * kTileStride + lane] = acc[ch];
+                        if (++staged == R) { flush(first, R); first += R; staged = 0; }
+                    }
                 }
-            }
+            };
+            int j = 0;
+            for (; j + kIlp <= lim; j += kIlp) rows(j, std::integral_constant<int, kIlp>{});
+            for (; j < lim; ++j) rows(j, std::integral_constant<int, 1>{});
         }
         if (STORE && staged) flush(first, staged);
     };
@@ -217,18 +251,22 @@ __global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restr
     }
 }
 
-int pick_vpt(int voices) {
-    int vpt = 4;
+// Voices per lane: 4 amortises the per-row scalar work best, but a lane walks its rows serially, so when the
+// launch is small (latency mode: one block) spread the voices over more waves instead of fewer, longer ones.
+int pick_vpt(int voices, int64_t nblocks) {
     const char* e = getenv("SIG_FUSED_VPT");
-    if (e) vpt = atoi(e);
-    if (vpt != 1 && vpt != 2 && vpt != 4) vpt = 4;
-    return vpt;                                                               // no alignment needs: nothing per-voice is stored
+    if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    for (int vpt = 4; vpt > 1; vpt >>= 1) {
+        const int64_t waves = ((voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt)) * nblocks;
+        if (waves >= 1024) return vpt;                                         // one wave per SIMD or more
+    }
+    return 1;
 }
 
 template <int KIND, bool GAIN, int C>
 int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
-    const int vpt = pick_vpt(a.voices);
+    const int vpt = pick_vpt(a.voices, a.K);
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -269,18 +307,125 @@ int dispatch_bus_kind(int kind, int C, const FusedArgs& a, const BusArgs& bus, f
     return (int)hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Latency mode: wavefront prefix-scan over TIME.  With one block per launch there are only `voices`
+// independent chains (16 waves for 1024 voices) and each lane walks c+N rows serially: ~50 us for N=256 on
+// an otherwise idle chip.  Here one WAVE owns one (voice, block) and its 64 lanes own consecutive chunks of
+// L = ceil((c+N)/64) rows.  The recurrence is affine in the state s = (z0, z1):
+//     s_n = A s_{n-1} + B x_n,   y_n = b0 x_n + z0_{n-1},   A = [[-a1, 1], [-a2, 0]]
+// so (1) every lane runs its chunk from ZERO state (local outputs + local end state e_l), (2) a 6-step
+// Hillis-Steele scan over the lanes with the matrices A^(L 2^k) turns the e_l into true chunk end states,
+// (3) every lane adds the homogeneous response of its true start state to its local outputs.
+// ~14 serial row steps + 6 scan steps instead of 356.  The scan reassociates the sums, so results match
+// the serial kernels to ~1e-13 (f64), not bit for bit.
+constexpr int kScanMaxL = 8;                                                  // rows per lane: c + N <= 512
+
+struct M2 { double a, b, c, d; };                                             // [[a, b], [c, d]]
+__device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
+    return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
+}
+
+template <int KIND, bool GAIN>
+__global__ __launch_bounds__(256) void fused_scan_kernel(FusedArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave = one (voice, block)
+    const int v = (int)(item % a.voices);
+    const int64_t b = item / a.voices;
+    if (b >= a.K) return;
+    const int64_t p_b = a.position + b * a.N;
+    const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+    const int64_t n0 = p_b - c;
+    const int total = c + a.N;
+    const int L = (total + SIG_WAVE - 1) / SIG_WAVE;                           // <= kScanMaxL (host-checked)
+
+    Biquad q;
+    const bool ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
+    if (!ok && a.status && lane == 0) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    const double hz = a.hertz[(int64_t)v * a.hs];
+    const double ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+    const double g = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
+
+    // (1) local pass from zero state
+    double yl[kScanMaxL];
+    double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kScanMaxL; ++k) {
+        const int r = lane * L + k;
+        const bool valid = (k < L) && (r < total);
+        const double t = (double)(n0 + r) / a.rate * hz + ph;                  // osc.py:32, same operator order
+        double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+        x = valid ? x : 0.0;
+        const double y = fma(q.b0, x, z0);
+        const double nz0 = fma(q.b1, x, fma(-q.a1, y, z1));
+        const double nz1 = fma(q.b2, x, -q.a2 * y);
+        yl[k] = y;
+        if (k < L) { z0 = nz0; z1 = nz1; }                                     // rows past the chunk do not exist
+    }
+
+    // (2) scan of chunk end states: S_l = M S_{l-1} + e_l,  M = A^L
+    const M2 A = {-q.a1, 1.0, -q.a2, 0.0};
+    M2 M = A;
+    for (int k = 1; k < L; ++k) M = m2_mul(A, M);
+    double s0 = z0, s1 = z1;
+#pragma unroll
+    for (int d = 1; d < SIG_WAVE; d <<= 1) {
+        const double p0 = __hiloint2double(__shfl_up(__double2hiint(s0), d, SIG_WAVE), __shfl_up(__double2loint(s0), d, SIG_WAVE));
+        const double p1 = __hiloint2double(__shfl_up(__double2hiint(s1), d, SIG_WAVE), __shfl_up(__double2loint(s1), d, SIG_WAVE));
+        if (lane >= d) {
+            s0 += fma(M.a, p0, M.b * p1);
+            s1 += fma(M.c, p0, M.d * p1);
+        }
+        M = m2_mul(M, M);
+    }
+    // true start state of this lane's chunk = end state of the previous lane's chunk
+    double t0 = __hiloint2double(__shfl_up(__double2hiint(s0), 1, SIG_WAVE), __shfl_up(__double2loint(s0), 1, SIG_WAVE));
+    double t1 = __hiloint2double(__shfl_up(__double2hiint(s1), 1, SIG_WAVE), __shfl_up(__double2loint(s1), 1, SIG_WAVE));
+    if (lane == 0) { t0 = 0.0; t1 = 0.0; }
+
+    // (3) homogeneous response of the start state, added to the local outputs
+    float* dst = a.out + (b * a.N - c) * a.out_ld + v;
+#pragma unroll
+    for (int k = 0; k < kScanMaxL; ++k) {
+        const int r = lane * L + k;
+        const double yh = t0;                                                  // y = b0*0 + z0
+        const double y = yl[k] + yh;
+        const double u0 = fma(-q.a1, yh, t1);
+        t1 = -q.a2 * yh;
+        t0 = u0;
+        if (k < L && r >= c && r < total) dst[(int64_t)r * a.out_ld] = (float)(GAIN ? y * g : y);
+    }
+}
+
+int pick_vpt(int voices, int64_t nblocks);
+
 int fused_variant() {
     static int v = [] { const char* e = getenv("SIG_FUSED_VPT"); return e ? atoi(e) : 0; }();
     return v;
 }
 
+// chains below which the serial walk leaves most of the chip idle (one wave per SIMD = 65536 lanes)
+constexpr int64_t kScanMaxChains = 16384;
+
 template <int KIND, bool GAIN>
 int launch_fused(FusedArgs a, hipStream_t stream)
 {
+    {
+        static const int scan_env = [] { const char* e = getenv("SIG_FUSED_SCAN"); return e ? atoi(e) : -1; }();
+        const int64_t chains = (int64_t)a.voices * a.K;
+        const bool fits = a.ctx + a.N <= kScanMaxL * SIG_WAVE;
+        const bool want = scan_env >= 0 ? scan_env != 0 : chains <= kScanMaxChains;
+        if (fits && want) {
+            const int64_t nwg = (chains + 3) / 4;
+            if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+            fused_scan_kernel<KIND, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a);
+            return sig_launch_status();
+        }
+    }
     auto ok = [&](int vpt) {
         return (a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0);
     };
-    int vpt = fused_variant() ? fused_variant() : 4;
+    int vpt = fused_variant() ? fused_variant() : pick_vpt(a.voices, a.K);
     while (vpt > 1 && !ok(vpt)) vpt >>= 1;
     if (!ok(vpt)) vpt = 1;
     const int span = SIG_WAVE * vpt;

@@ -38,6 +38,8 @@ from signals_amd.chain import (
 from signals_amd.chain import ext, files, fixed, fx, noise, osc, shape
 
 CONTEXT = 100
+SCAN_MAX_CHAINS = 16384      # signals_amd/csrc/fused_voice.hip: kScanMaxChains
+SCAN_MAX_ROWS = 512          # kScanMaxL * 64
 
 
 class NotBatchable(Exception):
@@ -88,6 +90,8 @@ class BatchRenderer:
         self._stream_end: int | None = None
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
+        self._replay = None                                # (graph version, N, K, launch(position)) of a one-launch plan
+        self.scan_max_chains = SCAN_MAX_CHAINS             # latency regime threshold (tests set 0 to force the serial kernels)
 
     # ------------------------------------------------------------------ public
     def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
@@ -95,6 +99,15 @@ class BatchRenderer:
         eager requests of `block_frames` frames."""
         if block_frames < 2:
             raise NotBatchable('block-rate (frames == 1) requests go through the eager path')
+        from signals_amd.chain import graph_clock
+        if self._replay is not None:
+            version, n, k, launch = self._replay
+            if version == graph_clock.version and (n, k) == (block_frames, nblocks):
+                # the whole graph is ONE fused launch with no history state: replay it at the new position
+                # without re-walking the graph (latency mode: ~10 us of host work per block)
+                self._stream_end = position + block_frames * nblocks
+                return launch(position)
+            self._replay = None
         continuing = self._stream_end == position and bool(self._tails)
         if not continuing:
             self._tails.clear()
@@ -109,6 +122,11 @@ class BatchRenderer:
     def reset(self) -> None:
         self._tails.clear()
         self._stream_end = None
+        self._replay = None
+
+    def _remember_replay(self, N: int, K: int, launch) -> None:
+        from signals_amd.chain import graph_clock
+        self._replay = (graph_clock.version, N, K, launch)
 
     # ------------------------------------------------------------------ kernel launch helper
     def _launch(self, name: str, fn: typing.Callable, **meta):
@@ -345,12 +363,23 @@ class _Batch:
         src = filt.input.sig
         if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
             return None
-        try:
-            hertz, phase = self._control(src.hertz, 'hertz'), self._control(src.phase, 'phase')
-            cutoff = self._control(filt.cutoff, 'cutoff')
-            gain = self._control(gain_node.right, 'right') if gain_node is not None else None
-        except NotBatchable:
+        ports = [src.hertz, src.phase, filt.cutoff] + ([gain_node.right] if gain_node is not None else [])
+        involved = [n for n in (src, filt, gain_node, bus_node) if n is not None]
+
+        def resolve():
+            """control rows as they are NOW (a Fixed re-uploads when its array changed); None if the pattern broke"""
+            if not all(n.get_state().enabled for n in involved):
+                return None
+            try:
+                rows_ = [self._control(p, p.name) for p in ports]
+            except NotBatchable:
+                return None
+            return rows_ + [None] * (4 - len(rows_))
+
+        resolved = resolve()
+        if resolved is None:
             return None
+        hertz, phase, cutoff, gain = resolved
         widths_ok = (max(hertz.shape[1], phase.shape[1]) == channels and cutoff.shape[1] == channels
                      and hertz.shape[1] in (1, channels) and phase.shape[1] in (1, channels)
                      and (gain is None or gain.shape[1] in (1, channels)))
@@ -369,18 +398,49 @@ class _Batch:
             need = _native.lib().sig_fused_voice_bus_workspace(channels, rows, bus_node.channels) // 8
             if o._workspace is None or o._workspace.numel() < need:
                 o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
-            o._launch(f'fused_voice_bus[{tag}]',
-                      lambda: _native.fused_voice_bus(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT, channels,
-                                                      hertz, phase, cutoff, gain, pan, result,
-                                                      workspace=o._workspace, status=status),
-                      units=rows * channels)
-            return result
-        result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=runtime.device())
-        o._launch(f'fused_osc_biquad[{tag}]',
-                  lambda: _native.fused_osc_biquad(kind, btype, self.rate, self.pos, self.N, self.K, CONTEXT,
-                                                   hertz, phase, cutoff, gain, result, status=status),
-                  units=rows * channels)
-        return result
+            N, K, rate, bus_c, dev = self.N, self.K, self.rate, bus_node.channels, runtime.device()
+            # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs
+            # as a time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
+            small = channels * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS
+
+            def launch_bus(position: int, out: torch.Tensor | None = None) -> torch.Tensor:
+                ctl = resolve()
+                pan_now = bus_node.resident_gains()
+                if ctl is None or any(a.shape != b.shape for a, b in zip(ctl[:3], (hertz, phase, cutoff))) or \
+                        (pan_now is None) != (pan is None):
+                    o._replay = None
+                    return o.render(position, N, K)                  # pattern no longer holds: re-plan
+                out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev) if out is None else out
+                if small:
+                    voices_buf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
+                    o._launch(f'fused_osc_biquad[{tag}]',
+                              lambda: _native.fused_osc_biquad(kind, btype, rate, position, N, K, CONTEXT,
+                                                               ctl[0], ctl[1], ctl[2], ctl[3], voices_buf, status=status),
+                              units=rows * channels)
+                    return o._launch('sum_bus', lambda: _native.sum_bus(voices_buf, pan_now, out), units=rows * channels)
+                return o._launch(f'fused_voice_bus[{tag}]',
+                                 lambda: _native.fused_voice_bus(kind, btype, rate, position, N, K, CONTEXT, channels,
+                                                                 ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
+                                                                 workspace=o._workspace, status=status),
+                                 units=rows * channels)
+            if node is o.node:
+                o._remember_replay(N, K, launch_bus)
+            return launch_bus(self.pos, result)
+        N, K, rate, dev = self.N, self.K, self.rate, runtime.device()
+
+        def launch_chain(position: int, out: torch.Tensor | None = None) -> torch.Tensor:
+            ctl = resolve()
+            if ctl is None or any(a.shape != b.shape for a, b in zip(ctl[:3], (hertz, phase, cutoff))):
+                o._replay = None
+                return o.render(position, N, K)
+            out = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev) if out is None else out
+            return o._launch(f'fused_osc_biquad[{tag}]',
+                             lambda: _native.fused_osc_biquad(kind, btype, rate, position, N, K, CONTEXT,
+                                                              ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
+                             units=rows * channels)
+        if node is o.node:
+            o._remember_replay(N, K, launch_chain)
+        return launch_chain(self.pos)
 
     # -------------------------------------------------------------- filters
     def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:

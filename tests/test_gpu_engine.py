@@ -17,10 +17,13 @@ def _gpu():
     _native.lib()
 
 
-def batched(node, position, frames, blocks, channels, fuse=False):
+def batched(node, position, frames, blocks, channels, fuse=False, scan=True):
     """fuse=False: one kernel per node, bit-identical to the eager path; fuse=True: the engine's default"""
     from signals_amd.engine import BatchRenderer
-    return BatchRenderer(node, channels, RATE, fuse=fuse).render(position, frames, blocks).cpu().numpy()
+    r = BatchRenderer(node, channels, RATE, fuse=fuse)
+    if not scan:
+        r.scan_max_chains = 0
+    return r.render(position, frames, blocks).cpu().numpy()
 
 
 def c2_graph(g, V=None, bus=False):
@@ -314,9 +317,13 @@ def test_fused_voice_bus_vs_oracle_and_unfused(golden):
     g = golden('c2')
     for tag, pos0 in (('p0', 0), ('p1h', HOUR)):
         timer = KernelTimer()
-        got = BatchRenderer(c2_graph(g, bus=True), 1, RATE, timer=timer).render(pos0, 256, 4).cpu().numpy()
+        r = BatchRenderer(c2_graph(g, bus=True), 1, RATE, timer=timer)
+        r.scan_max_chains = 0                               # 32 voices x 4 blocks would take the latency path
+        got = r.render(pos0, 256, 4).cpu().numpy()
         torch.cuda.synchronize()
         assert list(timer.summary()) == ['fused_voice_bus[Sine,lp,gain]']
+        small = BatchRenderer(c2_graph(g, bus=True), 1, RATE).render(pos0, 256, 4).cpu().numpy()   # scan chain + sum_bus
+        assert maxerr(small, got) < 1e-7                    # per-voice f32 rounding before the bus in the small path
         assert maxerr(got, f32(R.sum_bus(g[f'c2/{tag}']))) < 1e-7
         assert maxerr(got, batched(c2_graph(g, bus=True), pos0, 256, 4, 1)) < 1e-7
     rng = np.random.default_rng(13)
@@ -334,10 +341,62 @@ def test_fused_voice_bus_vs_oracle_and_unfused(golden):
             if gains is not None:
                 bus.get_state().gains = gains
             return bus
-        fused = batched(build(), 77, N, K, C, fuse=True)
+        fused = batched(build(), 77, N, K, C, fuse=True, scan=False)        # the bus-fused kernel itself
         plain = batched(build(), 77, N, K, C, fuse=False)
         scale = max(1.0, float(np.abs(plain).max()))
         assert fused.shape == (N * K, C) and maxerr(fused, plain) < 3e-7 * scale, (V, N, K, C, kind)
     # reproducible bit for bit, run to run
-    a = batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True)
-    assert np.array_equal(a, batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True))
+    a = batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True, scan=False)
+    assert np.array_equal(a, batched(c2_graph(g, bus=True), 0, 256, 4, 1, fuse=True, scan=False))
+
+
+def test_one_launch_replay_tracks_parameter_edits(golden):
+    """latency mode: a graph that is ONE fused launch is replayed per block without re-walking it; edits to a
+    Fixed's array (in place or replaced) and enable flags must still be seen, like the reference's shared arrays"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.chain.fixed import Fixed
+    from signals_amd.engine import BatchRenderer
+    g = golden('c2')
+    hz = g['c2/hertz'].copy()
+    src = mkosc('Sine', hz, g['c2/phase'])
+    f = fx.LowPass(); f.input = src; f.cutoff = fix(g['c2/cutoff'])
+    gn = fx.Gain(); gn.left = f; gn.right = fix(g['c2/gain'])
+    bus = ext.SumBus(); bus.input = gn
+    r = BatchRenderer(bus, 1, RATE)
+    a0 = r.render(0, 256, 1).cpu().numpy()
+    assert r._replay is not None
+    a1 = r.render(256, 256, 1).cpu().numpy()                        # replayed
+    ref = batched(c2_graph(g, bus=True), 0, 256, 2, 1, fuse=True)
+    assert np.array_equal(np.concatenate([a0, a1]), ref)
+    src.hertz.sig.get_state().value[0, :] *= 2.0                    # in-place edit of the shared array
+    b = r.render(512, 256, 1).cpu().numpy()
+    g2 = {k: g[k] for k in ('c2/hertz', 'c2/phase', 'c2/cutoff', 'c2/gain')}
+    g2['c2/hertz'] = g['c2/hertz'] * 2.0
+    assert np.array_equal(b, batched(c2_graph(g2, bus=True), 512, 256, 1, 1, fuse=True))
+    gn.get_state().enabled = False                                  # pattern broken -> re-plan -> zeros (1,1) into the bus
+    with pytest.raises(Exception):
+        r.render(768, 256, 1)                                       # SumBus over a one-row input is rejected, like eager would mis-shape
+
+
+def test_latency_mode_prefix_scan_kernel(golden):
+    """small launches run the voice chain as a wavefront prefix scan over time (fused_scan_kernel): same
+    values as the serial kernels to f64 reassociation error, golden parity unchanged"""
+    from signals_amd import _native
+    from signals_amd.chain import fx
+    f = golden('filter')
+    for fname, oname in (('LowPass', 'Sine'), ('HighPass', 'Sawtooth')):
+        for pos in (0, 50, 256, HOUR):                     # one block of 16 voices: scan path
+            flt = getattr(fx, fname)(); flt.input = mkosc(oname, f['filt/hertz'], f['filt/phase']); flt.cutoff = fix(f['filt/cutoff'])
+            got = batched(flt, pos, 256, 1, 16, fuse=True)
+            assert maxerr(got, f32(f[f'filt/{fname}/{oname}/p{pos}'])) < 3e-7, (fname, oname, pos)
+    # scan (V*K small) vs serial (forced by a big K) on the same voices; ragged sizes; gain stage
+    rng = np.random.default_rng(23)
+    mk = lambda lo, hi, V: torch.tensor(rng.uniform(lo, hi, (1, V)), device='cuda')
+    for V, N, ctx_pos in ((5, 33, 7), (64, 256, 0), (130, 412, 5000), (1024, 256, HOUR)):
+        hz, ph, cut, g = mk(55, 1760, V), mk(0, 1, V), mk(200, 8000, V), mk(0, 1, V)
+        scan = torch.empty((N, V), device='cuda')
+        _native.fused_osc_biquad('Triangle', 'lp', RATE, ctx_pos, N, 1, 100, hz, ph, cut, g, scan)
+        K = 17000 // V + 1                                  # enough chains that the serial kernel is chosen
+        serial = torch.empty((N * K, V), device='cuda')
+        _native.fused_osc_biquad('Triangle', 'lp', RATE, ctx_pos, N, K, 100, hz, ph, cut, g, serial)
+        assert float((scan - serial[:N]).abs().max()) < 2e-7, (V, N)
