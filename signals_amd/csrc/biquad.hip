@@ -241,7 +241,14 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
     }
     int vpt = variant ? variant / 100 : 4;
     int ring = variant ? variant % 100 : 8;
-    if (!ok(vpt)) { vpt = 1; ring = 8; }
+    if (!variant) {
+        // lanes walk rows serially: with few (voice tile, block) items prefer more, narrower waves and a deeper
+        // ring (big blocks x few blocks, e.g. N=1024 K=64, would otherwise leave 3/4 of the SIMDs idle)
+        while (vpt > 1 && (int64_t)((voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt)) * K < 2048) vpt >>= 1;
+        ring = (vpt == 4) ? 8 : 16;
+    }
+    while (vpt > 1 && !ok(vpt)) vpt >>= 1;
+    if (vpt == 1 && !variant) ring = 16;
     const int span = SIG_WAVE * vpt;
     const int voice_tiles = (voices + span - 1) / span;
     const int64_t items = (int64_t)voice_tiles * K;
