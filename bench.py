@@ -222,6 +222,7 @@ def main():
     latency = None
     if world == 1 and not args.single_mode:
         # latency mode: ONE 256-frame block per request, as a real-time sink would pull it
+        from signals_amd.chain import BlockLoc, Shape
         from signals_amd.chain.driver import BlockDriver
         from signals_amd.engine import BatchRenderer
         graph = build_graph(params, 0, V)
@@ -231,9 +232,8 @@ def main():
         drv.input = build_graph(params, 0, V)
         latency = {}
         for name, fn in (('engine_one_block_per_launch', lambda i: eng.render(i * N, N, 1)),
-                         ('eager_pull_one_block', lambda i: drv.input.request(
-                             __import__('signals_amd.chain', fromlist=['BlockLoc']).BlockLoc(
-                                 position=i * N, rate=RATE, shape=__import__('signals_amd.chain', fromlist=['Shape']).Shape(N, 2))))):
+                         ('eager_pull_one_block', lambda i: drv.input.request(BlockLoc(
+                             position=i * N, rate=RATE, shape=Shape(N, 2))))):
             for i in range(20):
                 fn(i)
             torch.cuda.synchronize()

@@ -53,6 +53,7 @@ class BlockDriver(Receiver):
         self.is_active = True
         self._engine = None
         self._engine_key = None
+        self._engine_ok = True
 
     @classmethod
     def flags(cls) -> SignalFlags:
@@ -69,13 +70,17 @@ class BlockDriver(Receiver):
         out[:, :] = block.detach().cpu().numpy()             # numpy broadcast, like dev.py:178
         return out
 
-    def pull(self, frames: typing.Optional[int] = None) -> np.ndarray:
-        """one callback's worth: (frames, channels) float32, then advance"""
+    def pull(self, frames: typing.Optional[int] = None, eager: bool = False) -> np.ndarray:
+        """One callback's worth: (frames, channels) float32, then advance.  By default the block goes through
+        the batched engine as a batch of one (a graph that fuses to one launch is replayed per block without
+        re-walking it); `eager=True`, or a graph the engine cannot schedule, uses the reference-shaped pull."""
         frames = self.blocksize if frames is None else frames
-        loc = BlockLoc(position=self.frame_position, rate=self.rate,
-                       shape=Shape(frames=frames, channels=self._state.channels))
         try:
-            block = self.input.request(loc)
+            block = None if eager else self._engine_render(frames, 1)
+            if block is None:
+                loc = BlockLoc(position=self.frame_position, rate=self.rate,
+                               shape=Shape(frames=frames, channels=self._state.channels))
+                block = self.input.request(loc)
             runtime.check_status()
         except Exception:
             self.is_active = False
@@ -83,21 +88,32 @@ class BlockDriver(Receiver):
         self.frame_position += frames
         return self._broadcast(block, frames)
 
+    def _engine_render(self, frames: int, nblocks: int) -> typing.Optional[torch.Tensor]:
+        """the input rendered by the batched engine, or None when the graph needs the eager path"""
+        from signals_amd import chain, engine
+        if not self.input or frames < 2:
+            return None
+        key = (chain.graph_clock.version, self.input.sig, self._state.channels, self.rate)
+        if self._engine_key != key:
+            self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate)
+            self._engine_key = key
+            self._engine_ok = True
+        if not self._engine_ok:
+            return None
+        try:
+            return self._engine.render(self.frame_position, frames, nblocks)
+        except engine.NotBatchable:
+            self._engine.reset()
+            self._engine_ok = False         # until the graph changes
+            return None
+
     def render(self, nblocks: int, frames: typing.Optional[int] = None, batched: bool = True) -> np.ndarray:
         """`nblocks` consecutive blocks as one (nblocks*frames, channels) array"""
-        from signals_amd import chain, engine
         frames = self.blocksize if frames is None else frames
-        if batched and self.input:
-            key = (chain.graph_clock.version, self.input.sig, self._state.channels, self.rate)
-            if self._engine_key != key:
-                self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate)
-                self._engine_key = key
-            try:
-                block = self._engine.render(self.frame_position, frames, nblocks)
+        if batched:
+            block = self._engine_render(frames, nblocks)
+            if block is not None:
                 runtime.check_status()
-            except engine.NotBatchable:
-                self._engine.reset()
-            else:
                 self.frame_position += frames * nblocks
                 return self._broadcast(block, frames * nblocks)
-        return np.concatenate([self.pull(frames) for _ in range(nblocks)])
+        return np.concatenate([self.pull(frames, eager=not batched) for _ in range(nblocks)])

@@ -141,7 +141,7 @@ def test_not_batchable_falls_back(golden):
     d = BlockDriver(); d.input = f1
     a = d.render(3)
     d2 = BlockDriver(); d2.input = f1
-    b = np.concatenate([d2.pull() for _ in range(3)])
+    b = np.concatenate([d2.pull(eager=True) for _ in range(3)])
     assert a.shape == (768, 1) and np.array_equal(a, b)
 
 
@@ -152,7 +152,8 @@ def test_driver_steps_like_the_callback(golden):
     out = d.render(4)
     assert d.frame_position == 1024 and d.tell() == 4 and out.shape == (1024, 1)
     d.seek(0)
-    assert maxerr(out[:256], d.pull()) < 2e-8          # render() may fuse Filter(Osc)xGain; pull() is the eager path
+    assert maxerr(out[:256], d.pull(eager=True)) < 2e-8   # render() may fuse Filter(Osc)xGain; eager pull does not
+    assert maxerr(out[256:512], d.pull()) < 2e-8          # default pull(): the engine, one block per launch
     stereo = BlockDriver(); stereo.get_state().channels = 2; stereo.input = c2_graph(g, bus=True)
     s = stereo.render(1)
     assert s.shape == (256, 2) and np.array_equal(s[:, 0], s[:, 1])       # (N,1) reply broadcast to 2 channels
