@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 1
+#define SIG_ABI_VERSION 2
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -56,6 +56,18 @@ int sig_osc_bank(int kind, int64_t position, int32_t rate, int64_t rows, int32_t
                  const double* hertz, int32_t hertz_stride,
                  const double* phase, int32_t phase_stride,   /* phase may be NULL = unplugged = 0 */
                  void* out, int32_t out_dtype, int64_t out_ld, void* stream);
+
+/* sig_osc_bank for launches whose control inputs change per block (Osc._eval reads hertz and phase through
+ * forward_at_block_rate, osc.py:28-30, so in a K-block batch they are K rows) and for block-RATE launches:
+ *   output row r is frame position + r * position_step and uses parameter row r / rows_per_param
+ *   (rows_per_param == 0: a single parameter row, the *_row_stride arguments are ignored).
+ * audio rate, per-block parameters: position_step = 1, rows_per_param = block_frames;
+ * block rate (what a control port sees for K blocks): position_step = block_frames, rows_per_param = 1. */
+int sig_osc_bank_mod(int kind, int64_t position, int64_t position_step, int32_t rate, int64_t rows,
+                     int32_t voices, int32_t rows_per_param,
+                     const double* hertz, int32_t hertz_stride, int64_t hertz_row_stride,
+                     const double* phase, int32_t phase_stride, int64_t phase_row_stride,
+                     void* out, int32_t out_dtype, int64_t out_ld, void* stream);
 
 /* Replaces CritFilter._filter + _get_sos (fx.py:85-121) for LowPass/HighPass (order 2 = one
  * biquad section), batched over `nblocks` consecutive blocks of `block_frames` frames.
@@ -94,6 +106,9 @@ typedef struct sig_operand {
     int64_t row_stride;
     int32_t col_stride;
     int32_t dtype;      /* SIG_F32 or SIG_F64 */
+    int32_t row_div;    /* > 1: output row r reads operand row r / row_div (a block-rate operand that changes per
+                           block in a batched launch: row_div = block_frames); 0 or 1: operand row = r */
+    int32_t reserved;
 } sig_operand;
 
 /* Replaces Gain/Mix/RingMod/Amp._eval (fx.py:35-60), arithmetic in f64:

@@ -18,7 +18,7 @@ FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 
-EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
+EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart')
 
@@ -29,7 +29,8 @@ class NativeError(RuntimeError):
 
 class Operand(ctypes.Structure):
     _fields_ = [('ptr', ctypes.c_void_p), ('row_stride', ctypes.c_int64),
-                ('col_stride', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+                ('col_stride', ctypes.c_int32), ('dtype', ctypes.c_int32),
+                ('row_div', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 _lib = None
@@ -73,7 +74,9 @@ def lib() -> ctypes.CDLL:
         L.sig_band_coldstart.restype = ctypes.c_int
         L.sig_band_coldstart.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, dp, i32,
                                          vp, i64, i64, vp, i64, i32, vp, vp]
-        if L.sig_abi_version() != 1:
+        L.sig_osc_bank_mod.restype = ctypes.c_int
+        L.sig_osc_bank_mod.argtypes = [ctypes.c_int, i64, i64, i32, i64, i32, i32, dp, i32, i64, dp, i32, i64, vp, i32, i64, vp]
+        if L.sig_abi_version() != 2:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
     return _lib
@@ -116,19 +119,44 @@ def _audio(t: torch.Tensor, what: str) -> None:
         raise NativeError(f'{what}: audio buffers are 2-D with contiguous channels, got strides {t.stride()}')
 
 
+def _ctrl_rows(t: torch.Tensor | None, what: str):
+    """(ptr, col_stride, row_stride, rows) of f64 control rows shaped (R, V) or (R, 1)"""
+    if t is None:
+        return None, 0, 0, 1
+    if t.dtype != torch.float64 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise NativeError(f'{what}: control rows are float64 (R,V) or (R,1) with contiguous channels, got '
+                          f'{tuple(t.shape)} {t.dtype}')
+    return t.data_ptr(), (0 if t.shape[1] == 1 else 1), (0 if t.shape[0] == 1 else t.stride(0)), t.shape[0]
+
+
 def osc_bank(kind: str, position: int, rate: int, hertz: torch.Tensor, phase: torch.Tensor | None,
-             out: torch.Tensor) -> torch.Tensor:
-    """out[(rows, voices)] <- oscillator `kind` starting at absolute frame `position`."""
+             out: torch.Tensor, step: int = 1, rows_per_param: int = 0) -> torch.Tensor:
+    """out[(rows, voices)] <- oscillator `kind`; row r is absolute frame `position + r*step`.
+    hertz/phase: (1|P, V|1) f64; with P > 1 parameter rows, output row r uses row r // rows_per_param."""
     _gpu(hertz, phase, out)
     _audio(out, 'osc out')
     rows, voices = out.shape
-    hp, hs = _ctrl_row(hertz, 'hertz')
-    pp, ps = _ctrl_row(phase, 'phase')
+    hp, hs, hrs, hrows = _ctrl_rows(hertz, 'hertz')
+    pp, ps, prs, prows = _ctrl_rows(phase, 'phase')
     for row, name in ((hertz, 'hertz'), (phase, 'phase')):
         if row is not None and row.shape[1] not in (1, voices):
             raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
-    _check(lib().sig_osc_bank(OSC_KINDS[kind], position, rate, rows, voices, hp, hs, pp, ps,
-                              out.data_ptr(), _dt(out), out.stride(0), _stream(out)), 'sig_osc_bank')
+    if step == 1 and hrows == 1 and prows == 1:
+        _check(lib().sig_osc_bank(OSC_KINDS[kind], position, rate, rows, voices, hp, hs, pp, ps,
+                                  out.data_ptr(), _dt(out), out.stride(0), _stream(out)), 'sig_osc_bank')
+        return out
+    if max(hrows, prows) > 1:
+        if rows_per_param < 1:
+            raise NativeError('per-block oscillator parameters need rows_per_param')
+        need = (rows + rows_per_param - 1) // rows_per_param
+        for n, name in ((hrows, 'hertz'), (prows, 'phase')):
+            if n not in (1, need):
+                raise NativeError(f'{name} has {n} parameter rows, launch needs 1 or {need}')
+    else:
+        rows_per_param = 0
+    _check(lib().sig_osc_bank_mod(OSC_KINDS[kind], position, step, rate, rows, voices, rows_per_param,
+                                  hp, hs, hrs, pp, ps, prs, out.data_ptr(), _dt(out), out.stride(0), _stream(out)),
+           'sig_osc_bank_mod')
     return out
 
 
@@ -164,11 +192,14 @@ def biquad_coldstart(btype: str, rate: int, position: int, block_frames: int, nb
 
 
 def _operand(t: torch.Tensor, rows: int, cols: int, what: str) -> Operand:
-    if t.dim() != 2 or t.shape[0] not in (1, rows) or t.shape[1] not in (1, cols):
+    """numpy-broadcast operand; an operand with R rows where rows % R == 0 is a per-block control operand
+    (R blocks of rows // R frames each)."""
+    if t.dim() != 2 or t.shape[1] not in (1, cols) or t.shape[0] < 1 or rows % t.shape[0]:
         raise NativeError(f'{what}: shape {tuple(t.shape)} does not broadcast to {(rows, cols)}')
     rs = 0 if t.shape[0] == 1 else t.stride(0)
     cs = 0 if t.shape[1] == 1 else t.stride(1)
-    return Operand(t.data_ptr(), rs, cs, _dt(t))
+    row_div = 0 if t.shape[0] in (1, rows) else rows // t.shape[0]
+    return Operand(t.data_ptr(), rs, cs, _dt(t), row_div, 0)
 
 
 def elementwise(op: str, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor | None, out: torch.Tensor) -> torch.Tensor:

@@ -6,10 +6,10 @@
 
 namespace {
 
-struct Opnd { const void* p; int64_t rs; int32_t cs; int32_t f64; };
+struct Opnd { const void* p; int64_t rs; int32_t cs; int32_t f64; int32_t rd; };   // rd: rows sharing one operand row (block-rate operands)
 
 __device__ __forceinline__ double ld_op(const Opnd& o, int64_t r, int v) {
-    const int64_t i = r * o.rs + (int64_t)v * o.cs;
+    const int64_t i = (o.rd > 1 ? r / o.rd : r) * o.rs + (int64_t)v * o.cs;
     return o.f64 ? ((const double*)o.p)[i] : (double)((const float*)o.p)[i];
 }
 
@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void ew_fast_kernel(int64_t rows, int cols, Op
     double ctl[4] = {0, 0, 0, 0};
     const Opnd& co = (OP == SIG_EW_MIX) ? c : b;
     if (OP != SIG_EW_RINGMOD) {
+        // one control row per launch, or per block (rd = block_frames, a multiple of this thread's 4 rows)
+        const int64_t crow = (co.rd > 1 ? r0 / co.rd : 0) * co.rs;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ctl[i] = ((const double*)co.p)[(int64_t)(v + i) * co.cs];
+        for (int i = 0; i < 4; ++i) ctl[i] = ((const double*)co.p)[crow + (int64_t)(v + i) * co.cs];
     }
     float4 xa[R], xb[R];
 #pragma unroll
@@ -81,9 +83,11 @@ __global__ __launch_bounds__(256) void ew_fast_kernel(int64_t rows, int cols, Op
 
 inline bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
 inline bool audio_fast(const Opnd& o, int cols) {
-    return !o.f64 && o.cs == 1 && o.rs >= cols && o.rs % 4 == 0 && aligned16(o.p);
+    return !o.f64 && o.cs == 1 && o.rs >= cols && o.rs % 4 == 0 && o.rd <= 1 && aligned16(o.p);
 }
-inline bool ctrl_fast(const Opnd& o) { return o.f64 && o.rs == 0 && (o.cs == 0 || o.cs == 1); }
+inline bool ctrl_fast(const Opnd& o) {
+    return o.f64 && (o.cs == 0 || o.cs == 1) && (o.rs == 0 || (o.rd >= 4 && o.rd % 4 == 0));
+}
 
 template <int OP>
 int launch_ew(int64_t rows, int cols, const Opnd& a, const Opnd& b, const Opnd& c,
@@ -114,8 +118,8 @@ int launch_ew(int64_t rows, int cols, const Opnd& a, const Opnd& b, const Opnd& 
 inline bool load_operand(const sig_operand* s, Opnd& o) {
     if (!s || !s->ptr) return false;
     if (s->dtype != SIG_F32 && s->dtype != SIG_F64) return false;
-    if (s->row_stride < 0 || s->col_stride < 0) return false;
-    o.p = s->ptr; o.rs = s->row_stride; o.cs = s->col_stride; o.f64 = (s->dtype == SIG_F64);
+    if (s->row_stride < 0 || s->col_stride < 0 || s->row_div < 0) return false;
+    o.p = s->ptr; o.rs = s->row_stride; o.cs = s->col_stride; o.f64 = (s->dtype == SIG_F64); o.rd = s->row_div;
     return true;
 }
 

@@ -141,16 +141,61 @@ class BatchRenderer:
         return word.tensor
 
 
+def _ctl_const(port: Receiver.BoundPort) -> bool:
+    """a control port whose value cannot change from block to block: unplugged, disabled, or a Fixed"""
+    src = port.sig
+    return src is None or not src.get_state().enabled or isinstance(src, fixed.Fixed)
+
+
+def _control_ports(node: Emitter) -> list:
+    """ports a node reads with forward_at_block_rate"""
+    if isinstance(node, osc.Osc):
+        return [node.hertz, node.phase]
+    if isinstance(node, (fx.Gain, fx.Amp)):
+        return [node.right]
+    if isinstance(node, fx.Mix):
+        return [node.mix]
+    if isinstance(node, fx.SingleCritFilter):
+        return [node.cutoff]
+    if isinstance(node, fx.DoubleCritFilter):
+        return [node.low, node.high]
+    if isinstance(node, ext.ADSR):
+        return [getattr(node, name) for name in _native.ADSR_PARAMS]
+    return []
+
+
+def _audio_ports(node: Emitter) -> list:
+    """ports a node reads at frame rate"""
+    if isinstance(node, (fx.Mix, fx.RingMod)):
+        return [node.left, node.right]
+    if isinstance(node, (fx.Gain, fx.Amp)):
+        return [node.left]
+    if isinstance(node, (fx.CritFilter, ext.SumBus, ext.MixMatrix, ext.Tap, files.FileWriter)):
+        return [node.input]
+    if isinstance(node, shape.Merge):
+        return [node.left, node.right]
+    return []
+
+
+def _modulated(node: Emitter | None) -> bool:
+    """some control input of this node is re-evaluated every block (an LFO on a cutoff, FM at block rate ...):
+    its reply to a block then depends on which request produced it, like a filter's (the block-rate value is
+    read at the REQUEST's position, chain/__init__.py:305-306), so its history rows come from tails, not from
+    re-rendering"""
+    return node is not None and any(not _ctl_const(p) for p in _control_ports(node))
+
+
 def _is_pure(node: Emitter | None, memo: dict) -> bool:
-    """position-pure: no filter anywhere upstream, so any row range can be rendered in one launch"""
-    if node is None:
+    """position-pure: no filter and no per-block control anywhere upstream on the audio path, so any row
+    range can be rendered in one launch and history rows can simply be re-rendered"""
+    if node is None or not node.get_state().enabled:
         return True
     if node not in memo:
         memo[node] = True       # cycles are rejected elsewhere
-        if isinstance(node, fx.CritFilter):
+        if isinstance(node, fx.CritFilter) or _modulated(node):
             memo[node] = False
-        elif isinstance(node, Receiver):
-            memo[node] = all(_is_pure(up, memo) for up in node.inputs_by_port.values())
+        else:
+            memo[node] = all(_is_pure(p.sig, memo) for p in _audio_ports(node))
     return memo[node]
 
 
@@ -166,9 +211,11 @@ class _Batch:
         self._memo: dict[tuple[Emitter, int], tuple[torch.Tensor, int]] = {}
         self._need: dict[tuple[Emitter, int], int] = {}
         self._impure: dict[Emitter, torch.Tensor] = {}
+        self._ctl_memo: dict[Emitter, torch.Tensor] = {}
 
     # -------------------------------------------------------------- control rows
-    def _control(self, port: Receiver.BoundPort, what: str) -> torch.Tensor:
+    def _control_const(self, port: Receiver.BoundPort, what: str) -> torch.Tensor:
+        """one (1, C) row that holds for every block (Fixed / unplugged); NotBatchable otherwise"""
         src = port.sig
         if src is None or not src.get_state().enabled:
             return Emitter.empty_result()
@@ -177,7 +224,47 @@ class _Batch:
             if row.shape[0] != 1:
                 raise NotBatchable(f'{what}: multi-row Fixed on a control port')
             return as_control(row)
-        raise NotBatchable(f'{what} is driven by {src.cls_name()}; only Fixed control sources are batched')
+        raise NotBatchable(f'{what} is driven by {src.cls_name()}; this stage needs block-invariant control rows')
+
+    def _control(self, port: Receiver.BoundPort, what: str) -> torch.Tensor:
+        """(1, C) if the value holds for every block, else (K, C): row b is the port's reply to the block-rate
+        request at position pos + b*N (forward_at_block_rate of block b)."""
+        return self._control_node(port.sig, what)
+
+    def _control_node(self, src: Emitter | None, what: str) -> torch.Tensor:
+        if src is None or not src.get_state().enabled:
+            return Emitter.empty_result()
+        if src in self._ctl_memo:
+            return self._ctl_memo[src]
+        o, K, dev = self.owner, self.K, runtime.device()
+        if isinstance(src, fixed.Fixed):
+            row = src.resident()
+            if row.shape[0] != 1:
+                raise NotBatchable(f'{what}: multi-row Fixed on a control port')
+            result = as_control(row)
+        elif isinstance(src, osc.Osc):
+            hertz, phase = self._control(src.hertz, 'hertz'), self._control(src.phase, 'phase')
+            _, voices = broadcast_shape((1, 1), hertz.shape[-2:], phase.shape[-2:])
+            result = torch.empty((K, voices), dtype=CTRL_DTYPE, device=dev)
+            o._launch(f'osc_bank[{src.kind()},block-rate]',
+                      lambda: _native.osc_bank(src.kind(), self.pos, self.rate, hertz, phase, result,
+                                               step=self.N, rows_per_param=1),
+                      units=K * voices)
+        elif isinstance(src, (fx.Gain, fx.Amp, fx.Mix, fx.RingMod)):
+            name = type(src).__name__
+            a = self._control(src.left, 'left')
+            b = self._control(src.right, 'right')
+            c = self._control(src.mix, 'mix') if isinstance(src, fx.Mix) else None
+            ops = [a, b] + ([c] if c is not None else [])
+            _, cols = broadcast_shape(*((1, t.shape[1]) for t in ops))
+            rows = max(t.shape[0] for t in ops)
+            result = torch.empty((rows, cols), dtype=CTRL_DTYPE, device=dev)
+            o._launch(f'elementwise[{name},block-rate]', lambda: _native.elementwise(name, a, b, c, result),
+                      units=rows * cols)
+        else:
+            raise NotBatchable(f'{what}: no block-rate schedule for {src.cls_name()}')
+        self._ctl_memo[src] = result
+        return result
 
     # -------------------------------------------------------------- history requirements
     def _require(self, node: Emitter | None, channels: int, hist: int) -> None:
@@ -192,6 +279,9 @@ class _Batch:
             return
         if isinstance(node, fx.CritFilter):
             self._require(node.input.sig, channels, min(CONTEXT, self.pos))
+        elif _modulated(node):
+            for port in _audio_ports(node):                       # own history comes from the tail / a fresh block
+                self._require(port.sig, channels, 0)
         elif isinstance(node, (fx.Mix, fx.RingMod)):
             self._require(node.left.sig, channels, hist)
             self._require(node.right.sig, channels, hist)
@@ -242,12 +332,21 @@ class _Batch:
         elif isinstance(node, osc.Osc):
             hertz = self._control(node.hertz, 'hertz')
             phase = self._control(node.phase, 'phase')
-            _, voices = broadcast_shape((1, 1), hertz.shape, phase.shape)
+            _, voices = broadcast_shape((1, 1), (1, hertz.shape[1]), (1, phase.shape[1]))
             result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
-            start = self.pos - hist
-            o._launch(f'osc_bank[{node.kind()}]',
-                      lambda: _native.osc_bank(node.kind(), start, self.rate, hertz, phase, result),
-                      units=rows * voices)
+            if _modulated(node):
+                # hertz / phase are re-read every block: K parameter rows, N output rows each
+                main = result[hist:]
+                o._launch(f'osc_bank[{node.kind()},per-block]',
+                          lambda: _native.osc_bank(node.kind(), self.pos, self.rate, hertz, phase, main,
+                                                   rows_per_param=self.N),
+                          units=main.shape[0] * voices)
+                self._own_history(node, voices, hist, result)
+            else:
+                start = self.pos - hist
+                o._launch(f'osc_bank[{node.kind()}]',
+                          lambda: _native.osc_bank(node.kind(), start, self.rate, hertz, phase, result),
+                          units=rows * voices)
 
         elif isinstance(node, noise.White):
             result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
@@ -258,21 +357,28 @@ class _Batch:
             result = self._filter(node, channels, hist, rows)
 
         elif isinstance(node, (fx.Mix, fx.RingMod, fx.Gain, fx.Amp)):
-            a = self._operand(node.left, channels, hist)
+            mod = _modulated(node)
+            in_hist = 0 if mod else hist                          # a modulated node's history comes from its tail
+            a = self._operand(node.left, channels, in_hist)
             if isinstance(node, (fx.Gain, fx.Amp)):
                 b, c = self._control(node.right, 'right'), None
             else:
-                b = self._operand(node.right, channels, hist)
+                b = self._operand(node.right, channels, in_hist)
                 c = self._control(node.mix, 'mix') if isinstance(node, fx.Mix) else None
-            shapes = [a.shape, b.shape] + ([c.shape] if c is not None else [])
-            r, cols = broadcast_shape(*shapes)
-            if r == 1:
-                result = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
+            ctl = c if isinstance(node, fx.Mix) else (b if isinstance(node, (fx.Gain, fx.Amp)) else None)
+            audio = [a] + ([b] if isinstance(node, (fx.Mix, fx.RingMod)) else [])
+            cols = broadcast_shape(*((1, t.shape[1]) for t in audio + ([ctl] if ctl is not None else [])))[1]
+            name = type(node).__name__
+            if all(t.shape[0] == 1 for t in audio) and not mod:
+                result = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)     # every operand is a one-row reply
+                o._launch(f'elementwise[{name}]', lambda: _native.elementwise(name, a, b, c, result), units=cols)
             else:
                 result = torch.empty((rows, cols), dtype=AUDIO_DTYPE, device=dev)
-            name = type(node).__name__
-            o._launch(f'elementwise[{name}]', lambda: _native.elementwise(name, a, b, c, result),
-                      units=result.shape[0] * cols)
+                main = result[hist:] if mod else result
+                o._launch(f'elementwise[{name}{",per-block" if mod else ""}]',
+                          lambda: _native.elementwise(name, a, b, c, main), units=main.shape[0] * cols)
+                if mod:
+                    self._own_history(node, cols, hist, result)
 
         elif isinstance(node, ext.SumBus):
             x = self._operand(node.input, node.input.channels, hist)
@@ -299,7 +405,7 @@ class _Batch:
                 raise NotBatchable('FileReader ran past the end of the file inside a batch')
 
         elif isinstance(node, ext.ADSR):
-            ctl = node.control_rows(lambda bound: self._control(bound, bound.name))
+            ctl = node.control_rows(lambda bound: self._control_const(bound, bound.name))
             _, voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))
             result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
             start = self.pos - hist
@@ -371,7 +477,7 @@ class _Batch:
             if not all(n.get_state().enabled for n in involved):
                 return None
             try:
-                rows_ = [self._control(p, p.name) for p in ports]
+                rows_ = [self._control_const(p, p.name) for p in ports]
             except NotBatchable:
                 return None
             return rows_ + [None] * (4 - len(rows_))
@@ -447,8 +553,8 @@ class _Batch:
         o = self.owner
         N, K, pos = self.N, self.K, self.pos
         band = isinstance(node, fx.DoubleCritFilter)
-        cutoff = self._control(node.low if band else node.cutoff, 'low' if band else 'cutoff')
-        high = self._control(node.high, 'high') if band else None
+        cutoff = self._control_const(node.low, 'low') if band else self._control(node.cutoff, 'cutoff')
+        high = self._control_const(node.high, 'high') if band else None
         c0 = min(CONTEXT, pos)
         src = node.input.sig
         pure_in = _is_pure(src, self._pure)
@@ -485,15 +591,22 @@ class _Batch:
                       lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
                                                        status=status),
                       units=N * K * channels)
-        if hist:
-            # this filter's own history rows: the previous batch's tail, or a fresh block [pos-hist, pos)
-            tail = o._tails.get(node) if self.continuing else None
-            if tail is not None and tail[0] == pos and tail[1].shape[0] >= hist and tail[1].shape[1] >= channels:
-                result[:hist].copy_(tail[1][tail[1].shape[0] - hist:, :channels])
-            else:
-                sub = _Batch(o, pos - hist, hist, 1, False)
-                result[:hist].copy_(sub.buffer(node, channels, 0))
+        self._own_history(node, channels, hist, result)
         return result
+
+    def _own_history(self, node: Emitter, channels: int, hist: int, result: torch.Tensor) -> None:
+        """rows [:hist] of a request-dependent node (filter, or a node with per-block control): the previous
+        batch's tail when the stream continues, else the node rendered as its own block [pos-hist, pos) -- what
+        the reference's block cache, respectively a fresh graph, would answer"""
+        if not hist:
+            return
+        o, pos = self.owner, self.pos
+        tail = o._tails.get(node) if self.continuing else None
+        if tail is not None and tail[0] == pos and tail[1].shape[0] >= hist and tail[1].shape[1] >= channels:
+            result[:hist].copy_(tail[1][tail[1].shape[0] - hist:, :channels])
+        else:
+            sub = _Batch(o, pos - hist, hist, 1, False)
+            result[:hist].copy_(sub.buffer(node, channels, 0))
 
     def impure_outputs(self):
         return self._impure.items()

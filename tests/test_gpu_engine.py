@@ -128,19 +128,20 @@ def test_not_batchable_falls_back(golden):
     from signals_amd.chain import fx
     from signals_amd.chain.driver import BlockDriver
     from signals_amd.engine import BatchRenderer, NotBatchable
-    g = golden('c2')
     lfo = mkosc('Sine', [[2.0]])
-    f = fx.LowPass(); f.input = mkosc('Sine', g['c2/hertz'], g['c2/phase'])
     scaled = fx.Gain(); scaled.left = lfo; scaled.right = fix([[500.0]])
     off = fx.Mix(); off.left = scaled; off.right = fix([[4000.0]]); off.mix = fix([[0.5]])
-    f.cutoff = off      # cutoff driven by an oscillator: eager only
-    # one-channel control rows do not index per voice in the reference either (IndexError) -> use 1 voice
+    # an oscillator-driven cutoff IS batched (block-rate launches) ...
     f1 = fx.LowPass(); f1.input = mkosc('Sine', [[440.0]]); f1.cutoff = off
+    assert np.array_equal(batched(f1, 0, 256, 3, 1), stream(f1, 0, 256, 3, 1))
+    # ... a FILTER inside a control path is not: block-rate filtering needs the eager request pattern
+    smooth = fx.LowPass(); smooth.input = off; smooth.cutoff = fix([[10.0]])
+    f2 = fx.LowPass(); f2.input = mkosc('Sine', [[440.0]]); f2.cutoff = smooth
     with pytest.raises(NotBatchable):
-        BatchRenderer(f1, 1, RATE).render(0, 256, 2)
-    d = BlockDriver(); d.input = f1
-    a = d.render(3)
-    d2 = BlockDriver(); d2.input = f1
+        BatchRenderer(f2, 1, RATE).render(0, 256, 2)
+    d = BlockDriver(); d.input = f2
+    a = d.render(3)                                          # falls back to block-by-block eager pulls
+    d2 = BlockDriver(); d2.input = f2
     b = np.concatenate([d2.pull(eager=True) for _ in range(3)])
     assert a.shape == (768, 1) and np.array_equal(a, b)
 
@@ -401,3 +402,61 @@ def test_latency_mode_prefix_scan_kernel(golden):
         serial = torch.empty((N * K, V), device='cuda')
         _native.fused_osc_biquad('Triangle', 'lp', RATE, ctx_pos, N, K, 100, hz, ph, cut, g, serial)
         assert float((scan - serial[:N]).abs().max()) < 2e-7, (V, N)
+
+
+def modulated_graph(g, V=32):
+    """FM at block rate + LFO-swept cutoff + tremolo: every control port fed by a computed block-rate signal"""
+    from signals_amd.chain import ext, fx
+    hz, ph, cut = g['c2/hertz'][:, :V], g['c2/phase'][:, :V], g['c2/cutoff'][:, :V]
+    lfo = mkosc('Sine', [[3.0]])                                        # one channel, shared
+    vib = fx.Gain(); vib.left = mkosc('Triangle', np.full((1, V), 5.0), ph); vib.right = fix([[12.0]])
+    fm = fx.Mix(); fm.left = vib; fm.right = fix(hz * 2.0); fm.mix = fix([[0.5]])     # hertz = 0.5*vib + hz
+    carrier = mkosc('Sawtooth', np.zeros((1, 1)), ph)
+    carrier.hertz = fm
+    sweep = fx.Gain(); sweep.left = lfo; sweep.right = fix([[0.4]])
+    one = fix([[1.0]])
+    depth = fx.Mix(); depth.left = sweep; depth.right = one; depth.mix = fix([[0.5]])   # 0.5*(0.4 lfo) + 0.5
+    cutoff = fx.RingMod(); cutoff.left = depth; cutoff.right = fix(cut * 2.0)           # block-rate product (1,V)
+    flt = fx.LowPass(); flt.input = carrier; flt.cutoff = cutoff
+    trem = fx.Gain(); trem.left = flt; trem.right = depth
+    bus = ext.SumBus(); bus.input = trem
+    return bus
+
+
+def test_per_block_control_inputs_batched_equals_eager(golden):
+    """control ports driven by oscillators / effects (read once per block at the block's position): the
+    engine evaluates them for all K blocks in block-rate launches; bitwise equal to the eager path, including
+    a filter reading history rows of a frequency-modulated oscillator across batch boundaries"""
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    ref = stream(modulated_graph(g), 0, 256, 6, 1)
+    timer = KernelTimer()
+    r = BatchRenderer(modulated_graph(g), 1, RATE, fuse=False, timer=timer)
+    got = torch.cat([r.render(0, 256, 2), r.render(512, 256, 3), r.render(1280, 256, 1)]).cpu().numpy()
+    torch.cuda.synchronize()
+    names = list(timer.summary())
+    assert any('block-rate' in n for n in names) and any('per-block' in n for n in names), names
+    assert np.array_equal(got, ref)
+    assert np.abs(ref).max() > 1e-3
+    # fresh start in the middle of the stream == a fresh eager graph asked for the same blocks
+    assert np.array_equal(batched(modulated_graph(g), 4096, 256, 3, 1), stream(modulated_graph(g), 4096, 256, 3, 1))
+    # default engine settings (fusion on: nothing here matches the fused pattern) agree too
+    assert np.array_equal(batched(modulated_graph(g), 0, 256, 6, 1, fuse=True), ref)
+
+
+def test_modulated_oscillator_vs_oracle(golden):
+    """the same kind of patch against the CPU oracle's pull protocol (float64)"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import fx
+    g = golden('c2')
+    V = 8
+    hz, ph = g['c2/hertz'][:, :V], g['c2/phase'][:, :V]
+    lfo = mkosc('Sine', [[2.0]])
+    dev = fx.Gain(); dev.left = lfo; dev.right = fix([[30.0]])
+    fm = fx.Mix(); fm.left = dev; fm.right = fix(hz * 2.0); fm.mix = fix([[0.5]])
+    car = mkosc('Sine', np.zeros((1, 1)), ph); car.hertz = fm
+    flt = fx.HighPass(); flt.input = car; flt.cutoff = fix(g['c2/cutoff'][:, :V])
+    o_fm = R.Binary('Mix', R.Binary('Gain', R.Osc('Sine', R.Fixed([[2.0]])), R.Fixed([[30.0]])), R.Fixed(hz * 2.0), R.Fixed([[0.5]]))
+    o_flt = R.Filter('hp', R.Osc('Sine', o_fm, R.Fixed(ph)), R.Fixed(g['c2/cutoff'][:, :V]))
+    ref = R.render_stream(o_flt, 0, 256, 4, V)
+    assert maxerr(batched(flt, 0, 256, 4, V), f32(ref)) < 3e-7
