@@ -101,6 +101,37 @@ def cpu_baseline(p, voices, frames, budget_s=12.0):
                        f'host has {os.cpu_count()} logical cores')
 
 
+def _cpu_worker(args):
+    p, lo, hi, frames, blocks = args
+    from oracle import chain_ref as R
+    import warnings
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    sl = slice(lo, hi)
+    node = R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(p['hertz'][:, sl]), R.Fixed(p['phase'][:, sl])),
+                                     R.Fixed(p['cutoff'][:, sl])), R.Fixed(p['gain'][:, sl]))
+    acc = 0.0
+    for b in range(blocks):
+        acc += float(R.sum_bus(R.render(node, b * frames, frames, hi - lo, RATE), p['pan'][:, sl]).sum())
+    return acc
+
+
+def cpu_baseline_sharded(p, voices, frames, workers, blocks=8):
+    """the same oracle with the voices sharded over host cores (one process per shard, like
+    the GPU path shards voices over GPUs); the per-shard stereo buses would be summed -- here only timed."""
+    import multiprocessing as mp
+    per = voices // workers
+    jobs = [(p, w * per, (w + 1) * per, frames, blocks) for w in range(workers)]
+    ctx = mp.get_context('fork')
+    with ctx.Pool(workers) as pool:
+        pool.map(_cpu_worker, [(p, 0, 4, frames, 1)] * workers)          # warm the workers (imports)
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, jobs)
+        dt = time.perf_counter() - t0
+    return dict(value=voices * frames * blocks / dt / 1e6, unit='Msamples/s', cores=workers, kind='port',
+                sample=f'{blocks} consecutive {frames}-frame blocks, {voices} voices sharded {per} per process over '
+                       f'{workers} processes, {dt:.1f} s')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -274,6 +305,9 @@ def main():
             line['latency_mode'] = latency
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(params, V, N)
+            workers = min(16, os.cpu_count() or 1)                      # the GPU box's CPU share for one GPU
+            if workers > 1 and V % workers == 0:
+                line['cpu_baseline_sharded'] = cpu_baseline_sharded(params, V, N, workers)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

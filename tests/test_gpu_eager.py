@@ -237,3 +237,29 @@ def test_band_filters_vs_scipy(cls, btype):
     from signals_amd.engine import BatchRenderer
     batch = BatchRenderer(build(), V, RATE).render(0, 256, 4).cpu().numpy()
     assert np.array_equal(batch, stream(build(), 0, 256, 4, V))
+
+
+def test_extreme_block_sizes_vs_oracle():
+    """ragged and maximum sizes: 1-frame-short context, a one-second block (48000 frames), 3 voices (not a multiple
+    of the 4-wide vector path), a position near 2^40, and empty launches through the C ABI"""
+    import ctypes
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    from signals_amd.chain import fx
+    rng = np.random.default_rng(41)
+    V = 3
+    hz, ph, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(200, 8000, (1, V))
+    for pos, n in ((99, 48000), (1, 2), (2 ** 40 - 17, 257)):
+        f = fx.LowPass(); f.input = mkosc('Sawtooth', hz, ph); f.cutoff = fix(cut)
+        got = render(f, pos, n, V)
+        ref = R.filter_block('lp', lambda p, k: R.osc('Sawtooth', p, k, RATE, hz, ph), pos, n, RATE, cut)
+        assert got.shape == (n, V) and maxerr(got, f32(ref)) < 3e-7, (pos, n)
+    # zero rows / zero voices: accepted, nothing launched, nothing touched
+    out = torch.full((4, 4), 7.0, device='cuda')
+    row = torch.ones((1, 4), dtype=torch.float64, device='cuda')
+    lib = _native.lib()
+    assert lib.sig_osc_bank(0, 0, RATE, 0, 4, row.data_ptr(), 1, None, 0, out.data_ptr(), 0, 4, None) == 0
+    assert lib.sig_osc_bank(0, 0, RATE, 4, 0, row.data_ptr(), 1, None, 0, out.data_ptr(), 0, 4, None) == 0
+    assert lib.sig_sum_bus(0, 4, out.data_ptr(), 4, 0, None, 0, 1, out.data_ptr(), 1, 0, None) == 0
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all())

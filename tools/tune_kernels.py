@@ -1,7 +1,8 @@
-"""scratch tuning harness (not part of the product): time kernel variants on the C2 shapes"""
+"""kernel tuning harness (not part of the product): times kernel variants on the C2 shapes through the C ABI.
+   TUNE={osc,bus,fused,fusedbus,walk} [SIG_BIQUAD_VARIANT=<vpt><ring>] [SIG_FUSED_VPT=n] [SIG_BIQUAD_WALK=n] python tools/tune_kernels.py"""
 import os, sys, subprocess, json
 import torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from signals_amd import _native, runtime
 runtime.set_device('cuda:0')
 V, N = 1024, 256
