@@ -115,7 +115,7 @@ def _cpu_worker(args):
     return acc
 
 
-def cpu_baseline_sharded(p, voices, frames, workers, blocks=8):
+def cpu_baseline_sharded(p, voices, frames, workers, blocks=128):
     """the same oracle with the voices sharded over host cores (one process per shard, like
     the GPU path shards voices over GPUs); the per-shard stereo buses would be summed -- here only timed."""
     import multiprocessing as mp
@@ -146,6 +146,12 @@ def main():
     ap.add_argument('--materialised', action='store_true', help='headline = one kernel per node (no fusion)')
     ap.add_argument('--single-mode', action='store_true', help='skip the second (alternative schedule) measurement')
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  RCCL prints its version banner to stdout (fd 1) when the first
+    # communicator is created, so everything but the final line is sent to stderr at the fd level.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -308,7 +314,8 @@ def main():
             workers = min(16, os.cpu_count() or 1)                      # the GPU box's CPU share for one GPU
             if workers > 1 and V % workers == 0:
                 line['cpu_baseline_sharded'] = cpu_baseline_sharded(params, V, N, workers)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
