@@ -12,6 +12,8 @@
 //      k-step ks (A[i][k] wants one float per lane);
 //   3. M's B operands (M[32h+ks][32jt + (lane&31)]) live in 64 VGPRs for the wave's lifetime;
 //   4. 2 x 32 MFMAs, then the 32x32 accumulators are stored as 128-B row segments.
+#include <cstdlib>
+
 #include "sig_common.h"
 
 namespace {
@@ -98,7 +100,10 @@ extern "C" int sig_mix_matrix(int64_t rows, int32_t voices, const float* x, int6
     const int64_t row_tiles = (rows + kTileRows - 1) / kTileRows;
     const int64_t items = row_tiles * groups;
     int64_t nwg = (items + kWaves - 1) / kWaves;
-    if (nwg > 256 * 16) nwg = 256 * 16;                 // persistent-ish: each wave strides over items, M stays in VGPRs
+    // persistent: the register budget (M's 64 B-operand VGPRs + A + accumulators) admits 2 workgroups per CU;
+    // launch exactly that many so M is fetched once per wave and every wave strides over many tiles
+    static const int64_t cap = [] { const char* e = getenv("SIG_MIXMAT_WGS"); return e ? atoll(e) : 512LL; }();
+    if (nwg > cap) nwg = cap;
     mix_matrix_kernel<<<(unsigned)nwg, 256, 0, static_cast<hipStream_t>(stream)>>>(rows, groups, x, x_ld, matrix, out, out_ld, row_tiles);
     return sig_launch_status();
 }
