@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8
 ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
               'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
               'fused_voice_bus': 2 * 2 * 8 / 256 + 2 * 4 / 1024}   # f64 tile partials (written, re-read) + f32 stereo bus
-F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 25, 'fused_voice_bus': 26}   # f64-rate VALU instructions per (voice, row), ISA count
+F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 21, 'fused_voice_bus': 22}   # f64-rate VALU instructions per (voice, row), ISA count
 
 
 def synth_params(total_voices: int):

@@ -3,11 +3,12 @@
 // else consumes (and, optionally, feeds a Gain nobody else consumes): the oscillator samples never touch
 // HBM, so the stage costs 4 B/voice-sample (the store) instead of 4 + 8 (+ 8).
 //
-// Same arithmetic as the node kernels (sig_osc.h, sig_biquad.h; reference osc.py:26-62, fx.py:85-121,
-// fx.py:51-52): f64 phase, f64 recurrence from zero state over [c context rows | block], context rows are
-// recomputed (the oscillator is position-pure), the filter input is the oscillator's f64 sample rather
-// than its f32-rounded store, and the gain multiplies the f64 filter output before the single f32
-// rounding -- i.e. strictly closer to the f64 reference than the materialised path.
+// Same design and phase arithmetic as the node kernels (sig_osc.h, sig_biquad.h; reference osc.py:26-62,
+// fx.py:85-121, fx.py:51-52): f64 phase, f64 recurrence from zero state over [c context rows | block], context
+// rows are recomputed (the oscillator is position-pure), the filter input is the oscillator's f64 sample
+// rather than its f32-rounded store, the recurrence uses fused multiply-adds (one rounding per FMA instead of
+// sosfilt's two), and the gain multiplies the f64 filter output before the single f32 rounding -- i.e.
+// closer to the exact f64 recurrence than the materialised path, and 1e-6-parity with the reference.
 //
 // Mapping: one wave = 64*VPT consecutive voices of ONE block, lanes walk c+N rows serially; the per-row
 // quotient n/rate (IEEE f64 divide) is computed 64 rows at a time, one row per lane, and broadcast with
@@ -102,9 +103,11 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
 #pragma unroll
                     for (int i = 0; i < VPT; ++i) {
                         const double x = xs[u][i];
-                        const double y = q[i].b0 * x + z0[i];                 // scipy _sosfilt order, contract off
-                        z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
-                        z1[i] = q[i].b2 * x - q[i].a2 * y;
+                        // DF2T with fused multiply-adds: 5 f64 ops instead of sosfilt's 8 separately rounded ones (this
+                        // kernel is f64-issue-bound; the per-node biquad kernels keep scipy's exact operation order)
+                        const double y = fma(q[i].b0, x, z0[i]);
+                        z0[i] = fma(q[i].b1, x, fma(-q[i].a1, y, z1[i]));
+                        z1[i] = fma(q[i].b2, x, -q[i].a2 * y);
                         if (STORE) y32[i] = (float)(GAIN ? y * g[i] : y);
                     }
                     if (STORE && live) {
@@ -214,9 +217,9 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
 #pragma unroll
                     for (int i = 0; i < VPT; ++i) {
                         const double x = xs[u][i];
-                        const double y = q[i].b0 * x + z0[i];
-                        z0[i] = q[i].b1 * x - q[i].a1 * y + z1[i];
-                        z1[i] = q[i].b2 * x - q[i].a2 * y;
+                        const double y = fma(q[i].b0, x, z0[i]);              // fused DF2T, see fused_osc_biquad_kernel
+                        z0[i] = fma(q[i].b1, x, fma(-q[i].a1, y, z1[i]));
+                        z1[i] = fma(q[i].b2, x, -q[i].a2 * y);
                         if (STORE) {
 #pragma unroll
                             for (int ch = 0; ch < C; ++ch) acc[ch] = fma(w[ch][i], y, acc[ch]);

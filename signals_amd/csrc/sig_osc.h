@@ -44,7 +44,7 @@ __device__ __forceinline__ SinePhase sine_phase(double t) {
     const double a = t * kTwoPi;
     const double e = fma(t, kTwoPi, -a);                // a + e == t * 2fl(pi) exactly
     p.s = fma(t, kTwoPiTail, e);
-    const double u = (t + t) + kRoundMagic;             // low mantissa bits = rint(2t)
+    const double u = fma(t, 2.0, kRoundMagic);          // = fl(2t + M): low mantissa bits = rint(2t)
     const double k = u - kRoundMagic;                   // exact
     p.rq = fma(k, -0.5, t);                             // exact, |rq| <= 0.25
     p.flip = ((unsigned)__double2loint(u) & 1u) << 31;  // parity of K
