@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8
 ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
               'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
               'fused_voice_bus': 2 * 2 * 8 / 256 + 2 * 4 / 1024}   # f64 tile partials (written, re-read) + f32 stereo bus
-F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 21, 'fused_voice_bus': 22}   # f64-rate VALU instructions per (voice, row), ISA count
+F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 12, 'fused_voice_bus': 13}   # f64-rate VALU instructions per (voice, row), ISA count
 
 
 def synth_params(total_voices: int):
@@ -239,8 +239,9 @@ def main():
                                'avg_launch_ms': kernels[dom]['avg_ms']}
             if dom.split('[')[0] in F64_INSTR_PER_UPDATE:
                 # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
-                # the meaningful ceiling is the f64 vector issue rate.  Instructions per (voice, row) update are
-                # counted in the ISA; (N+c)/N updates per stored sample (context rows recomputed);
+                # the meaningful ceiling is the f64 vector issue rate.  f64-rate instructions per (voice, row) update,
+                # counted in the ISA: 4 phase (fast Sine path) + 2 cvt + 5 fused DF2T + 2 bus FMAs (or
+                # 1 gain mul); (N+c)/N updates per stored sample (context rows are recomputed);
                 # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
                 upd = (summ[dom]['units'] / summ[dom]['calls']) * (N + 100) / N
                 ach = F64_INSTR_PER_UPDATE[dom.split('[')[0]] * upd / (kernels[dom]['avg_ms'] * 1e-3) / 1e12

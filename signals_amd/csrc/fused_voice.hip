@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
     const int total = c + a.N;
 
     Biquad q[VPT];
-    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], g[VPT];
+    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], g[VPT], dr[VPT];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
         ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
         g[i] = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
         z0[i] = 0.0; z1[i] = 0.0;
+        const double d = hz[i] / a.rate;                                       // revolutions per row
+        dr[i] = d - rint(d);
     }
     if (!ok && live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
@@ -82,19 +84,42 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
         for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
             const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
             const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
+            // Sine: advance the phase by hertz/rate per row inside the chunk when every |t| of the wave is small
+            bool fast = false;
+            double f0[VPT];
+            if (KIND == SIG_OSC_SINE) {
+                bool small = true;
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const double t_first = sig_readlane_f64(q_lane, 0) * hz[i] + ph[i];
+                    const double t_last = sig_readlane_f64(q_lane, lim - 1) * hz[i] + ph[i];
+                    small &= fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT;
+                    f0[i] = t_first - rint(t_first);                           // exact
+                }
+                fast = __all(small);
+            }
             // oscillator samples of kIlp rows are independent of the filter state: compute them first so their
             // long dependent chains overlap, then run the (serial) recurrence over them
             auto rows = [&](int j, auto count_tag) {
                 constexpr int CNT = decltype(count_tag)::value;
                 double xs[CNT][VPT];
+                if (KIND == SIG_OSC_SINE && fast) {
 #pragma unroll
-                for (int u = 0; u < CNT; ++u) {
-                    const double t_s = sig_readlane_f64(q_lane, j + u);
+                    for (int u = 0; u < CNT; ++u) {
+                        const double jj = (double)(j + u);
 #pragma unroll
-                    for (int i = 0; i < VPT; ++i) {
-                        const double t = t_s * hz[i] + ph[i];
-                        xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                           : sig_osc::osc_wave<KIND, double>(t);
+                        for (int i = 0; i < VPT; ++i) xs[u][i] = (double)sig_osc::osc_sine_f32_fast(f0[i], dr[i], jj);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CNT; ++u) {
+                        const double t_s = sig_readlane_f64(q_lane, j + u);
+#pragma unroll
+                        for (int i = 0; i < VPT; ++i) {
+                            const double t = t_s * hz[i] + ph[i];
+                            xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                               : sig_osc::osc_wave<KIND, double>(t);
+                        }
                     }
                 }
 #pragma unroll
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
     const int total = c + a.N;
 
     Biquad q[VPT];
-    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], w[C][VPT];
+    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], dr[VPT], w[C][VPT];
     bool ok = true, any_live = false;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -173,6 +198,8 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
         for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0
             w[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * gn : gn) : 0.0;   // pan * gain, once per voice
         z0[i] = 0.0; z1[i] = 0.0;
+        const double d = hz[i] / a.rate;                                       // revolutions per row
+        dr[i] = d - rint(d);
     }
     if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
@@ -194,19 +221,42 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
         constexpr bool STORE = decltype(store_tag)::value;
         int staged = 0, first = r_begin - c;
         for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
-            const double q_lane = (double)(n0 + r0 + lane) / a.rate;
+            const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
             const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
+            // Sine: advance the phase by hertz/rate per row inside the chunk when every |t| of the wave is small
+            bool fast = false;
+            double f0[VPT];
+            if (KIND == SIG_OSC_SINE) {
+                bool small = true;
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const double t_first = sig_readlane_f64(q_lane, 0) * hz[i] + ph[i];
+                    const double t_last = sig_readlane_f64(q_lane, lim - 1) * hz[i] + ph[i];
+                    small &= fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT;
+                    f0[i] = t_first - rint(t_first);                           // exact
+                }
+                fast = __all(small);
+            }
             auto rows = [&](int j, auto count_tag) {
                 constexpr int CNT = decltype(count_tag)::value;
                 double xs[CNT][VPT];
+                if (KIND == SIG_OSC_SINE && fast) {
 #pragma unroll
-                for (int u = 0; u < CNT; ++u) {
-                    const double t_s = sig_readlane_f64(q_lane, j + u);
+                    for (int u = 0; u < CNT; ++u) {
+                        const double jj = (double)(j + u);
 #pragma unroll
-                    for (int i = 0; i < VPT; ++i) {
-                        const double t = t_s * hz[i] + ph[i];
-                        xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                           : sig_osc::osc_wave<KIND, double>(t);
+                        for (int i = 0; i < VPT; ++i) xs[u][i] = (double)sig_osc::osc_sine_f32_fast(f0[i], dr[i], jj);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CNT; ++u) {
+                        const double t_s = sig_readlane_f64(q_lane, j + u);
+#pragma unroll
+                        for (int i = 0; i < VPT; ++i) {
+                            const double t = t_s * hz[i] + ph[i];
+                            xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
+                                                               : sig_osc::osc_wave<KIND, double>(t);
+                        }
                     }
                 }
 #pragma unroll

@@ -83,6 +83,23 @@ __device__ __forceinline__ float osc_sine_f32(double t) {
     return __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(rev)) ^ p.flip);
 }
 
+// Fast Sine phase for f64-issue-bound kernels that walk consecutive rows: within a chunk of rows the phase
+// advances by d = hertz/rate revolutions per row, so  t_j ~ t_0 + j*d  and only frac(t_0) (exact) and d are
+// needed.  Relative to the exact path this drops (a) the tracking of numpy's own argument rounding,
+// |fl(t*2pi) - 2pi*t| <= 9.4e-16*|t| rad, and (b) the roundings inside fl(fl(n/rate)*hertz)+phase, <= ulp(t)
+// cycles: both < 2.5e-8 rad while |t| < 2^24 cycles, which the caller checks per wave (kSineFastMaxT); beyond
+// that the exact path is used.  f_j = fma(j, d, f0) is a single rounding from exact operands, no accumulation.
+constexpr double kSineFastMaxT = 16777216.0;            // 2^24 cycles (2.6 h at 1760 Hz)
+
+__device__ __forceinline__ float osc_sine_f32_fast(double f0, double d, double j) {
+    const double f = fma(j, d, f0);                     // |f| <= 0.5 + 64*0.5
+    const double u = fma(f, 2.0, kRoundMagic);
+    const double k = u - kRoundMagic;
+    const float rev = (float)fma(k, -0.5, f);           // |rev| <= 0.25
+    const unsigned flip = ((unsigned)__double2loint(u) & 1u) << 31;
+    return __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(rev)) ^ flip);
+}
+
 template <int KIND, typename OUT> __device__ __forceinline__ OUT osc_wave(double t) {
     if (KIND == SIG_OSC_SINE) {
         if (sizeof(OUT) == 4) return (OUT)osc_sine_f32(t);

@@ -460,3 +460,25 @@ def test_modulated_oscillator_vs_oracle(golden):
     o_flt = R.Filter('hp', R.Osc('Sine', o_fm, R.Fixed(ph)), R.Fixed(g['c2/cutoff'][:, :V]))
     ref = R.render_stream(o_flt, 0, 256, 4, V)
     assert maxerr(batched(flt, 0, 256, 4, V), f32(ref)) < 3e-7
+
+
+def test_fused_sine_fast_and_exact_phase_paths():
+    """the fused kernels advance the Sine phase incrementally while every |t| of a wave is < 2^24 cycles and use
+    the exact path (numpy's argument rounding tracked) beyond; both within 1e-6 of the reference arithmetic,
+    including across the switch-over and at positions where float64 has ~1e-5 cycles of resolution left"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    rng = np.random.default_rng(29)
+    V = 64
+    hz, ph, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(200, 8000, (1, V))
+    hz[0, 0], hz[0, 1] = 23999.0, 0.01                       # near Nyquist / nearly DC
+
+    def build():
+        f = fx.LowPass(); f.input = mkosc('Sine', hz, ph); f.cutoff = fix(cut)
+        return f
+    switch = int(2 ** 24 / 1760 * RATE)                      # where the 1760 Hz voices cross 2^24 cycles
+    for pos in (0, HOUR, switch - 300, 10 * HOUR, 2 ** 40):
+        got = batched(build(), pos, 256, 3, V, fuse=True, scan=False)
+        ref = np.concatenate([R.filter_block('lp', lambda p, n: R.osc('Sine', p, n, RATE, hz, ph), pos + b * 256, 256,
+                                             RATE, cut) for b in range(3)])
+        assert maxerr(got, f32(ref)) < 4e-7, pos
