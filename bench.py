@@ -6,8 +6,8 @@ Workload (BASELINE.json configs[1]): per GPU a 1024-voice
 the batched engine, one step = one batch of `--blocks` (default 1024) consecutive 256-frame blocks of synthetic
 parameters (numpy default_rng(0): hertz U(55,1760), phase U(0,1), cutoff U(200,8000), gain U(0,1)/V,
 pan theta U(0,pi/2)), already resident in HBM.  With N > 1 GPUs every rank renders its own 1024 voices
-(weak scaling, no data-path traffic) and the stereo bus is summed across ranks with one RCCL
-all-reduce per batch (the path's only exchange step).
+(weak scaling, no data-path traffic) and the stereo bus is summed onto rank 0 with one RCCL reduce per
+batch (the path's only exchange step), overlapped with the next batch's kernels.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--voices V] [--frames F]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -187,7 +187,7 @@ def main():
             # (K*N, 2) f32 bus: local render, then the RCCL all-reduce of THIS batch is left in flight on
             # RCCL's stream while the next batch renders; it is waited for one step later (and at the fence)
             nonlocal pos, pending
-            bus, work = renderer.render_async(pos, N, K)
+            bus, work = renderer.render_async(pos, N, K, dst=0)        # the sink lives on rank 0: reduce, not all-reduce
             pos += N * K
             if pending is not None:
                 pending.wait()
@@ -300,7 +300,7 @@ def main():
                                    f'{N}-frame blocks, {K} blocks per batch (f32 storage, f64 phase/recurrence); '
                                    f'engine schedule = {describe(not args.materialised)}',
                        'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
-                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL all-reduce of the stereo bus'},
+                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL reduce of the stereo bus to rank 0, async'},
         }
         for k in ('roofline', 'kernels'):
             if k in main_mode:

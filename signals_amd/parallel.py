@@ -76,10 +76,11 @@ class ShardedRenderer:
         self.lo, self.hi = shard_voices(total_voices, self.world, self.rank, group)
         self.renderer = BatchRenderer(build(self.lo, self.hi), bus_channels, rate, timer=timer, fuse=fuse)
 
-    def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
-        return reduce_bus(self.renderer.render(position, block_frames, nblocks))
+    def render(self, position: int, block_frames: int, nblocks: int, dst: typing.Optional[int] = None) -> torch.Tensor:
+        """the mixed bus on every rank (dst None: all-reduce) or on rank `dst` only (reduce: half the traffic)"""
+        return reduce_bus(self.renderer.render(position, block_frames, nblocks), dst=dst)
 
-    def render_async(self, position: int, block_frames: int, nblocks: int):
-        """(bus, work): the bus all-reduce of this batch overlaps the next batch's kernels; `work.wait()`
+    def render_async(self, position: int, block_frames: int, nblocks: int, dst: typing.Optional[int] = None):
+        """(bus, work): the bus reduction of this batch overlaps the next batch's kernels; `work.wait()`
         (if not None) before the bus is read."""
-        return reduce_bus(self.renderer.render(position, block_frames, nblocks), async_op=True)
+        return reduce_bus(self.renderer.render(position, block_frames, nblocks), dst=dst, async_op=True)
