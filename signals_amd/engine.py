@@ -17,8 +17,20 @@ cascaded filters:
 The reference's `after(100)` requests never reach kept samples (sosfilt is causal) and, for constant
 block size N > 100, never serve a later request from the cache; they are skipped here.
 
-Graphs that do not fit (control ports driven by anything but `Fixed`, cascaded filters with
-N <= 100, unknown node classes) raise `NotBatchable`; callers fall back to the eager path.
+Control inputs (forward_at_block_rate) that are not constant -- an LFO on a cutoff, block-rate FM -- are
+evaluated for all K blocks in block-rate launches and handed to their consumers as K parameter rows; a
+node with such an input answers differently depending on which request produced a frame range (the
+control value is read at the REQUEST's position), so, like a filter, its history rows come from the
+previous batch's tail or from a fresh block, never from re-rendering.
+
+With `fuse=True` (default) `[SumBus(] [Gain(] LowPass|HighPass(Osc) [)] [)]` runs as one fused launch
+when nothing else consumes the intermediates; a graph that is exactly one such launch is replayed per
+call without re-walking it (latency mode).  `fuse=False` is one kernel per node and bit-identical to the
+eager path.
+
+Graphs that do not fit (a filter inside a control path, per-block ADSR / band-filter parameters,
+cascaded filters with N <= 100, unknown node classes) raise `NotBatchable`; callers fall back to the
+eager path (`BlockDriver` does so by itself).
 """
 from __future__ import annotations
 
@@ -75,11 +87,16 @@ class KernelTimer:
 
 
 class BatchRenderer:
+    """Renders `node` (as seen through a request of `channels` channels at `rate`) in batches of consecutive
+    blocks.  Keeps what a stream needs between batches: the last <=100 rows of every request-dependent
+    node (tails), the device status words of its filters, and the replay closure of a one-launch plan."""
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
                  fuse: bool = True, fuse_bus: bool = True):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
-        no other consumer (sig_fused_osc_biquad).  Off = one kernel per node, bit-identical to the eager path."""
+        no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
+        (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
+        `timer`: optional KernelTimer that brackets every launch with HIP events."""
         self.fuse = fuse
         self.fuse_bus = fuse and fuse_bus           # also fold a SumBus on top of the chain into the launch
         self.node = node
