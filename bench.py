@@ -160,7 +160,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
 
     from signals_amd import _native, runtime
-    runtime.set_device(f'cuda:{local_rank}')
+    runtime.set_device(f'cuda:{local_rank % torch.cuda.device_count()}')
     _native.lib()
     from signals_amd import parallel
     from signals_amd.engine import KernelTimer

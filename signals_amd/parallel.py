@@ -41,11 +41,12 @@ def init_process_group() -> tuple[int, int]:
         os.environ.setdefault('WORLD_SIZE', '1')
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if torch.cuda.is_available():
+        backend = os.environ.get('SIG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if backend == 'nccl':
             local = int(os.environ.get('LOCAL_RANK', '0'))
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local % torch.cuda.device_count()))
         else:
-            dist.init_process_group('gloo')
+            dist.init_process_group(backend)          # gloo: CPU tests, or a multi-rank rehearsal on one GPU
     return rank, world
 
 
