@@ -463,12 +463,12 @@ class _Batch:
     # -------------------------------------------------------------- fusion
     def _try_fuse(self, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
         """[SumBus(] [Gain(] LowPass|HighPass(Osc) [)] [)] -> one launch, when nothing else reads the
-        intermediates and nobody needs this node's history rows.  None when the pattern does not apply."""
-        if hist != 0:
-            return None
+        intermediates.  The chain form also serves a consumer that needs history rows (a second filter): the
+        launch writes the K blocks and the `hist` rows in front come from the tail / a fresh block like any
+        filter's.  None when the pattern does not apply."""
         bus_node, top = None, node
         if isinstance(node, ext.SumBus):
-            if not self.owner.fuse_bus:
+            if not self.owner.fuse_bus or hist != 0:
                 return None
             bus_node, top = node, node.input.sig
             if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
@@ -550,6 +550,16 @@ class _Batch:
                 o._remember_replay(N, K, launch_bus)
             return launch_bus(self.pos, result)
         N, K, rate, dev = self.N, self.K, self.rate, runtime.device()
+
+        if hist:
+            result = torch.empty((hist + rows, channels), dtype=AUDIO_DTYPE, device=dev)
+            main = result[hist:]
+            o._launch(f'fused_osc_biquad[{tag}]',
+                      lambda: _native.fused_osc_biquad(kind, btype, rate, self.pos, N, K, CONTEXT,
+                                                       hertz, phase, cutoff, gain, main, status=status),
+                      units=rows * channels)
+            self._own_history(node, channels, hist, result)
+            return result
 
         def launch_chain(position: int, out: torch.Tensor | None = None) -> torch.Tensor:
             ctl = resolve()

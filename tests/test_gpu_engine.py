@@ -482,3 +482,23 @@ def test_fused_sine_fast_and_exact_phase_paths():
         ref = np.concatenate([R.filter_block('lp', lambda p, n: R.osc('Sine', p, n, RATE, hz, ph), pos + b * 256, 256,
                                              RATE, cut) for b in range(3)])
         assert maxerr(got, f32(ref)) < 4e-7, pos
+
+
+def test_fused_first_stage_of_a_cascade(golden):
+    """LowPass(LowPass(Osc)): the inner Filter(Osc) runs fused even though the outer filter needs its history
+    rows (tail of the previous batch / fresh block); golden cascade parity and continuity across batches"""
+    from signals_amd.chain import fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    c = golden('cascade')
+
+    def build():
+        f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', c['casc/hertz'], c['casc/phase']); f1.cutoff = fix(c['casc/cut1'])
+        f2 = fx.LowPass(); f2.input = f1; f2.cutoff = fix(c['casc/cut2'])
+        return f2
+    timer = KernelTimer()
+    r = BatchRenderer(build(), 8, RATE, timer=timer)
+    got = torch.cat([r.render(0, 256, 1), r.render(256, 256, 2), r.render(768, 256, 1)]).cpu().numpy()
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'fused_osc_biquad[Sawtooth,lp]', 'biquad_coldstart[lp]'}
+    assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
+    assert maxerr(batched(build(), 768, 256, 1, 8, fuse=True), batched(build(), 768, 256, 1, 8)) < 3e-7     # fresh start
