@@ -398,10 +398,21 @@ class _Batch:
                     self._own_history(node, cols, hist, result)
 
         elif isinstance(node, ext.SumBus):
-            x = self._operand(node.input, node.input.channels, hist)
+            src_port, gains = node.input, node.resident_gains()
+            top = node.input.sig
+            if (o.fuse and isinstance(top, fx.Gain) and top.get_state().enabled and _ctl_const(top.right)
+                    and len(top.outputs_with_ports) == 1 and top.left.sig is not None):
+                # a per-voice Gain feeding only this bus is a diagonal scaling of the mix weights:
+                # sum_v pan[c,v] * (g[v] * x[n,v]) = sum_v (pan[c,v] * g[v]) * x[n,v]  -- fold it, skip the launch
+                g = self._control_const(top.right, 'right')
+                voices = top.left.channels
+                if g.shape[1] in (1, voices) and (gains is None or gains.shape[1] == voices):
+                    gains = (gains * g) if gains is not None else g.expand(1, voices).contiguous()
+                    src_port = top.left
+                    self._require(src_port.sig, voices, hist)
+            x = self._operand(src_port, src_port.channels, hist)
             if x.shape[0] == 1:
                 raise NotBatchable('SumBus over a one-row input')
-            gains = node.resident_gains()
             result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=dev)
             o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
 

@@ -502,3 +502,31 @@ def test_fused_first_stage_of_a_cascade(golden):
     assert set(timer.summary()) == {'fused_osc_biquad[Sawtooth,lp]', 'biquad_coldstart[lp]'}
     assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
     assert maxerr(batched(build(), 768, 256, 1, 8, fuse=True), batched(build(), 768, 256, 1, 8)) < 3e-7     # fresh start
+
+
+def test_gain_folded_into_bus_weights(golden):
+    """SumBus(Gain(X, Fixed)) with no other consumer of the Gain: the engine folds the gain row into the bus
+    weights instead of launching the Gain kernel (any X: here a cascade and a RingMod, mono and stereo)"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    V = 32
+    rng = np.random.default_rng(31)
+    pan = np.stack([np.cos(rng.uniform(0, 1.5, V)), np.sin(rng.uniform(0, 1.5, V))])
+
+    def build(stereo):
+        f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', g['c2/hertz'], g['c2/phase']); f1.cutoff = fix(g['c2/cutoff'])
+        f2 = fx.HighPass(); f2.input = f1; f2.cutoff = fix(g['c2/cutoff'] * 0.25)
+        rm = fx.RingMod(); rm.left = f2; rm.right = mkosc('Sine', [[3.0]])
+        gn = fx.Gain(); gn.left = rm; gn.right = fix(g['c2/gain'])
+        bus = ext.SumBus(); bus.input = gn
+        if stereo:
+            bus.get_state().gains = pan
+        return bus
+    for stereo in (False, True):
+        C = 2 if stereo else 1
+        timer = KernelTimer()
+        got = BatchRenderer(build(stereo), C, RATE, timer=timer).render(0, 256, 4).cpu().numpy()
+        torch.cuda.synchronize()
+        assert 'elementwise[Gain]' not in timer.summary() and 'sum_bus' in timer.summary()
+        assert maxerr(got, batched(build(stereo), 0, 256, 4, C)) < 1e-7
