@@ -12,7 +12,6 @@ import torch
 
 from signals_amd import SignalFlags, _native, runtime
 from signals_amd.chain import (
-    CTRL_DTYPE,
     BlockCachingEmitter,
     ImplicitChannels,
     Receiver,
