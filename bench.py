@@ -269,7 +269,9 @@ def main():
         drv.get_state().channels = 2
         drv.input = build_graph(params, 0, V)
         latency = {}
+        eng_graph = BatchRenderer(build_graph(params, 0, V), 2, RATE, graph_replay=True)
         for name, fn in (('engine_one_block_per_launch', lambda i: eng.render(i * N, N, 1)),
+                         ('engine_hipgraph_replay', lambda i: eng_graph.render(i * N, N, 1)),
                          ('eager_pull_one_block', lambda i: drv.input.request(BlockLoc(
                              position=i * N, rate=RATE, shape=Shape(N, 2))))):
             for i in range(20):

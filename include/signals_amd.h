@@ -162,6 +162,17 @@ int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t posi
                          const double* gain, int32_t gain_stride,
                          float* out, int64_t out_ld, int32_t* status, void* stream);
 
+/* hipGraph support for the launch-bound latency loop (one block per pull): the same chain with the frame
+ * position read from DEVICE memory, plus a one-thread kernel that advances it, so a captured graph
+ * [chain(position_dev) -> bus -> position_dev += block_frames*nblocks] replays unchanged block after block. */
+int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const int64_t* position_dev,
+                                int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                const double* cutoff, int32_t cutoff_stride,
+                                const double* gain, int32_t gain_stride,
+                                float* out, int64_t out_ld, int32_t* status, void* stream);
+int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
+
 /* Fused voice chain + sum bus:  out[n,c] = sum_v bus_gains[c,v] * ([gain[v] *] Filter(Osc)[n,v])
  * (bus_gains == NULL: bus_channels == 1, plain sum).  Nothing per-voice touches HBM.  Two launches inside:
  * the chain kernel writes per-voice-tile f64 partials into `workspace` (device, at least

@@ -20,7 +20,8 @@ STATUS_BAD_CUTOFF = 1
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
-           'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart')
+           'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
+           'sig_fused_osc_biquad_devpos', 'sig_advance_position')
 
 
 class NativeError(RuntimeError):
@@ -76,6 +77,11 @@ def lib() -> ctypes.CDLL:
                                          vp, i64, i64, vp, i64, i32, vp, vp]
         L.sig_osc_bank_mod.restype = ctypes.c_int
         L.sig_osc_bank_mod.argtypes = [ctypes.c_int, i64, i64, i32, i64, i32, i32, dp, i32, i64, dp, i32, i64, vp, i32, i64, vp]
+        L.sig_fused_osc_biquad_devpos.restype = ctypes.c_int
+        L.sig_fused_osc_biquad_devpos.argtypes = [ctypes.c_int, ctypes.c_int, i32, vp, i32, i32, i32, i32,
+                                                  dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
+        L.sig_advance_position.restype = ctypes.c_int
+        L.sig_advance_position.argtypes = [vp, i64, vp]
         if L.sig_abi_version() != 2:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
@@ -272,10 +278,11 @@ def mix_matrix(x: torch.Tensor, matrix: torch.Tensor, out: torch.Tensor) -> torc
     return out
 
 
-def fused_osc_biquad(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+def fused_osc_biquad(kind: str, btype: str, rate: int, position, block_frames: int, nblocks: int, context: int,
                      hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
                      gain: torch.Tensor | None, out: torch.Tensor, status: torch.Tensor | None = None) -> torch.Tensor:
-    """out (nblocks*block_frames, voices) f32 <- [gain *] Filter(Osc), every block cold-started"""
+    """out (nblocks*block_frames, voices) f32 <- [gain *] Filter(Osc), every block cold-started.
+    `position`: an int, or a one-element int64 device tensor read by the kernel (hipGraph replay)."""
     _gpu(hertz, phase, cutoff, gain, out, status)
     _audio(out, 'fused out')
     rows, voices = out.shape
@@ -286,11 +293,25 @@ def fused_osc_biquad(kind: str, btype: str, rate: int, position: int, block_fram
         if row is not None and row.shape[1] not in (1, voices):
             raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
         ptrs.extend(_ctrl_row(row, name))
+    if isinstance(position, torch.Tensor):
+        if position.dtype != torch.int64 or position.numel() != 1 or not position.is_cuda:
+            raise NativeError('device position must be a one-element int64 GPU tensor')
+        _check(lib().sig_fused_osc_biquad_devpos(OSC_KINDS[kind], FILT_TYPES[btype], rate, position.data_ptr(), block_frames,
+                                                 nblocks, context, voices, *ptrs, out.data_ptr(), out.stride(0),
+                                                 status.data_ptr() if status is not None else None, _stream(out)),
+               'sig_fused_osc_biquad_devpos')
+        return out
     _check(lib().sig_fused_osc_biquad(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
                                       voices, *ptrs, out.data_ptr(), out.stride(0),
                                       status.data_ptr() if status is not None else None, _stream(out)),
            'sig_fused_osc_biquad')
     return out
+
+
+def advance_position(position: torch.Tensor, delta: int) -> None:
+    """position[0] += delta on the device, in stream order"""
+    _gpu(position)
+    _check(lib().sig_advance_position(position.data_ptr(), delta, _stream(position)), 'sig_advance_position')
 
 
 def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,

@@ -95,7 +95,8 @@ class BlockDriver(Receiver):
             return None
         key = (chain.graph_clock.version, self.input.sig, self._state.channels, self.rate)
         if self._engine_key != key:
-            self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate)
+            # pull() copies every block to the host before asking for the next: graph-owned buffers are safe
+            self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate, graph_replay=True)
             self._engine_key = key
             self._engine_ok = True
         if not self._engine_ok:

@@ -40,6 +40,7 @@ struct FusedArgs {
     const double* hertz; int hs; const double* phase; int ps;
     const double* cutoff; int cs; const double* gain; int gs;
     float* out; int64_t out_ld; int voice_tiles; int* status;
+    const int64_t* pos_dev = nullptr;        // when set, the position is read from device memory (hipGraph replay)
 };
 
 template <int KIND, int VPT, bool GAIN>
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
     const bool live = v0 < a.voices;
     const int vc = live ? v0 : 0;
 
-    const int64_t p_b = a.position + b * a.N;
+    const int64_t p_b = (a.pos_dev ? *a.pos_dev : a.position) + b * a.N;
     const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
     const int64_t n0 = p_b - c;                                               // absolute frame of row 0
     const int total = c + a.N;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusAr
     if (b >= a.K) return;                                                     // wave-uniform
     const int v0 = (vt * SIG_WAVE + lane) * VPT;
 
-    const int64_t p_b = a.position + b * a.N;
+    const int64_t p_b = (a.pos_dev ? *a.pos_dev : a.position) + b * a.N;
     const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
     const int64_t n0 = p_b - c;
     const int total = c + a.N;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(FusedArgs a)
     const int v = (int)(item % a.voices);
     const int64_t b = item / a.voices;
     if (b >= a.K) return;
-    const int64_t p_b = a.position + b * a.N;
+    const int64_t p_b = (a.pos_dev ? *a.pos_dev : a.position) + b * a.N;
     const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
     const int64_t n0 = p_b - c;
     const int total = c + a.N;
@@ -525,6 +526,36 @@ extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, i
                 out, out_ld, 0, status};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
+}
+
+extern "C" int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const int64_t* position_dev,
+                                           int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                           const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                           const double* cutoff, int32_t cutoff_stride,
+                                           const double* gain, int32_t gain_stride,
+                                           float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position_dev && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, 0, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                out, out_ld, 0, status, position_dev};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
+}
+
+namespace {
+__global__ void advance_kernel(int64_t* p, int64_t delta) { *p += delta; }
+}  // namespace
+
+extern "C" int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream)
+{
+    SIG_CHECK_ARG(position_dev != nullptr);
+    advance_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(position_dev, delta);
+    return sig_launch_status();
 }
 
 extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)

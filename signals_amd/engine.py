@@ -86,17 +86,54 @@ class KernelTimer:
         self.records.clear()
 
 
+class _CapturedLaunches:
+    """A short launch sequence captured once into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed per
+    call: the frame position lives in a device int64 that the kernels read and the graph's last node
+    advances, so consecutive blocks replay with no host work beyond one graph launch.  The output buffer is
+    owned by the graph and overwritten by every replay."""
+
+    def __init__(self, record: typing.Callable[[torch.Tensor], torch.Tensor], advance: int, position: int, keys: tuple):
+        dev = runtime.device()
+        self.keys = keys                                    # identities of the tensors baked into the graph
+        self.advance = advance
+        self.pos = torch.tensor([position], dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up outside capture, as graph capture requires
+            record(self.pos)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.pos.fill_(position)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = record(self.pos)
+            _native.advance_position(self.pos, advance)
+        self.pos.fill_(position)
+        self.next_position = position
+
+    def run(self, position: int) -> torch.Tensor:
+        if position != self.next_position:
+            self.pos.fill_(position)                        # seek
+        self.graph.replay()
+        self.next_position = position + self.advance
+        return self.out
+
+
 class BatchRenderer:
     """Renders `node` (as seen through a request of `channels` channels at `rate`) in batches of consecutive
     blocks.  Keeps what a stream needs between batches: the last <=100 rows of every request-dependent
     node (tails), the device status words of its filters, and the replay closure of a one-launch plan."""
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
-                 fuse: bool = True, fuse_bus: bool = True):
+                 fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
-        `timer`: optional KernelTimer that brackets every launch with HIP events."""
+        `timer`: optional KernelTimer that brackets every launch with HIP events.
+        `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
+        and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
+        render -- only for callers that consume each block before asking for the next (BlockDriver.pull)."""
+        self.graph_replay = graph_replay and timer is None
+        self._captured: _CapturedLaunches | None = None
         self.fuse = fuse
         self.fuse_bus = fuse and fuse_bus           # also fold a SumBus on top of the chain into the launch
         self.node = node
@@ -140,6 +177,7 @@ class BatchRenderer:
         self._tails.clear()
         self._stream_end = None
         self._replay = None
+        self._captured = None
 
     def _remember_replay(self, N: int, K: int, launch) -> None:
         from signals_amd.chain import graph_clock
@@ -544,6 +582,18 @@ class _Batch:
                         (pan_now is None) != (pan is None):
                     o._replay = None
                     return o.render(position, N, K)                  # pattern no longer holds: re-plan
+                if small and o.graph_replay and out is None:
+                    keys = tuple(t.data_ptr() if t is not None else 0 for t in (*ctl, pan_now))
+                    cap = o._captured
+                    if cap is None or cap.keys != keys:
+                        def record(pos_t: torch.Tensor) -> torch.Tensor:
+                            vbuf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
+                            bus_out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
+                            _native.fused_osc_biquad(kind, btype, rate, pos_t, N, K, CONTEXT,
+                                                     ctl[0], ctl[1], ctl[2], ctl[3], vbuf, status=status)
+                            return _native.sum_bus(vbuf, pan_now, bus_out)
+                        cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
+                    return cap.run(position)
                 out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev) if out is None else out
                 if small:
                     voices_buf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)

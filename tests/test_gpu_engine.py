@@ -530,3 +530,35 @@ def test_gain_folded_into_bus_weights(golden):
         torch.cuda.synchronize()
         assert 'elementwise[Gain]' not in timer.summary() and 'sum_bus' in timer.summary()
         assert maxerr(got, batched(build(stereo), 0, 256, 4, C)) < 1e-7
+
+
+def test_hipgraph_replay_of_the_latency_loop(golden):
+    """graph_replay=True: [scan chain(position on device) -> sum_bus -> position += N] captured once into a
+    hipGraph and replayed per block; same bits as the uncaptured launches, across seeks and parameter edits"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer
+    g = golden('c2')
+    hz = g['c2/hertz'].copy()
+
+    def build(hertz):
+        f = fx.LowPass(); f.input = mkosc('Sine', hertz, g['c2/phase']); f.cutoff = fix(g['c2/cutoff'])
+        gn = fx.Gain(); gn.left = f; gn.right = fix(g['c2/gain'])
+        bus = ext.SumBus(); bus.input = gn
+        return bus, f.input.sig.hertz.sig
+    node, hz_fixed = build(hz)
+    r = BatchRenderer(node, 1, RATE, graph_replay=True)
+    plain = BatchRenderer(build(hz)[0], 1, RATE)
+    positions = [0, 256, 512, 768, 4096, 4352, 256]                # sequential, a seek forward, a seek back
+    for pos in positions:
+        a = r.render(pos, 256, 1).clone()                           # graph-owned buffer: copy before the next call
+        assert torch.equal(a, plain.render(pos, 256, 1)), pos
+    assert r._captured is not None
+    hz_fixed.get_state().value = hz * 1.5                           # new array -> new upload -> re-capture
+    plain2 = BatchRenderer(build(hz * 1.5)[0], 1, RATE)
+    for pos in (512, 768):
+        assert torch.equal(r.render(pos, 256, 1).clone(), plain2.render(pos, 256, 1)), pos
+    from signals_amd.chain.driver import BlockDriver
+    d = BlockDriver(); d.input = build(hz)[0]
+    e = BlockDriver(); e.input = build(hz)[0]
+    pulled = np.concatenate([d.pull() for _ in range(6)])
+    assert maxerr(pulled, np.concatenate([e.pull(eager=True) for _ in range(6)])) < 1e-7
