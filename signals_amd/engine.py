@@ -592,8 +592,14 @@ class _Batch:
                             _native.fused_osc_biquad(kind, btype, rate, pos_t, N, K, CONTEXT,
                                                      ctl[0], ctl[1], ctl[2], ctl[3], vbuf, status=status)
                             return _native.sum_bus(vbuf, pan_now, bus_out)
-                        cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
-                    return cap.run(position)
+                        try:
+                            cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
+                        except RuntimeError:
+                            # capture refused (another capture in progress, a profiler that forbids it ...):
+                            # keep rendering with plain launches
+                            o.graph_replay, o._captured, cap = False, None, None
+                    if cap is not None:
+                        return cap.run(position)
                 out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev) if out is None else out
                 if small:
                     voices_buf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
