@@ -116,3 +116,20 @@ def test_span_walker_is_bit_identical_to_the_plain_biquad_kernel(params):
         r = BatchRenderer(build(), V, RATE, fuse=False)
         parts = torch.cat([r.render(pos + i * 64 * N, N, 64) for i in range(8)])
         assert torch.equal(whole, parts), pos
+
+
+def test_c4_eight_shards_of_1024_voices_sum_to_the_unsharded_bus():
+    """BASELINE config 4 on one GPU: the 8192-voice graph rendered as 8 shards of 1024 voices (what 8 ranks do,
+    `shard_voices`), buses summed in rank order like the RCCL reduce, against the same graph rendered unsharded"""
+    from signals_amd.engine import BatchRenderer
+    from signals_amd.parallel import shard_voices
+    total, world, k = 8192, 8, 16
+    p = bench.synth_params(total)
+    whole = BatchRenderer(bench.build_graph(p, 0, total), 2, RATE).render(0, N, k).double()
+    acc = torch.zeros_like(whole)
+    for rank in range(world):
+        lo, hi = shard_voices(total, world, rank)
+        assert hi - lo == 1024
+        acc += BatchRenderer(bench.build_graph(p, lo, hi), 2, RATE).render(0, N, k).double()
+    assert float((acc - whole).abs().max()) < 1e-7          # summation order differs: rounding-level agreement
+    assert float(whole.abs().max()) > 1e-4
