@@ -359,144 +359,30 @@ class _Batch:
         return full[have - hist:] if have != hist else full
 
     def _materialise(self, node: Emitter | None, channels: int) -> tuple[torch.Tensor, int]:
+        """(buffer, history rows it carries) of one node for this batch, memoised per (node, channels)"""
         key = (node, channels)
         if key in self._memo:
             return self._memo[key]
-        hist = self._need[key] if node is not None else 0
-        rows = hist + self.N * self.K
-        dev = runtime.device()
-        o = self.owner
         if node is not None and isinstance(node, (ext.Tap, files.FileWriter)) and not node.get_state().enabled:
             self._memo[key] = self._materialise(node.input.sig, channels)      # PASSTHRU: disabled = forward input
             return self._memo[key]
         if node is None or not node.get_state().enabled:
-            result = Emitter.empty_result()                       # (1,1) zeros broadcast everywhere
-            self._memo[key] = (result, 0)
+            self._memo[key] = (Emitter.empty_result(), 0)                      # (1,1) zeros broadcast everywhere
             return self._memo[key]
+        hist = self._need[key]
+        rows = hist + self.N * self.K
 
-        fused = self._try_fuse(node, channels, hist) if o.fuse else None
-        if fused is not None:
-            result = fused
-
-        elif isinstance(node, fixed.Fixed):
-            value = node.resident()
-            if value.shape[0] != 1:
-                raise NotBatchable('multi-row Fixed as an audio source')
-            result = value
-
-        elif isinstance(node, osc.Osc):
-            hertz = self._control(node.hertz, 'hertz')
-            phase = self._control(node.phase, 'phase')
-            _, voices = broadcast_shape((1, 1), (1, hertz.shape[1]), (1, phase.shape[1]))
-            result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
-            if _modulated(node):
-                # hertz / phase are re-read every block: K parameter rows, N output rows each
-                main = result[hist:]
-                o._launch(f'osc_bank[{node.kind()},per-block]',
-                          lambda: _native.osc_bank(node.kind(), self.pos, self.rate, hertz, phase, main,
-                                                   rows_per_param=self.N),
-                          units=main.shape[0] * voices)
-                self._own_history(node, voices, hist, result)
+        result = _VoiceChain.match_and_launch(self, node, channels, hist) if self.owner.fuse else None
+        if result is None:
+            for types, build in self._SCHEDULES:
+                if isinstance(node, types):
+                    result = build(self, node, channels, hist, rows)
+                    break
             else:
-                start = self.pos - hist
-                o._launch(f'osc_bank[{node.kind()}]',
-                          lambda: _native.osc_bank(node.kind(), start, self.rate, hertz, phase, result),
-                          units=rows * voices)
-
-        elif isinstance(node, noise.White):
-            result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
-            seed, start = node.get_state().seed, self.pos - hist
-            o._launch('white_noise', lambda: _native.white_noise(seed, start, result), units=rows * channels)
-
-        elif isinstance(node, fx.CritFilter):
-            result = self._filter(node, channels, hist, rows)
-
-        elif isinstance(node, (fx.Mix, fx.RingMod, fx.Gain, fx.Amp)):
-            mod = _modulated(node)
-            in_hist = 0 if mod else hist                          # a modulated node's history comes from its tail
-            a = self._operand(node.left, channels, in_hist)
-            if isinstance(node, (fx.Gain, fx.Amp)):
-                b, c = self._control(node.right, 'right'), None
-            else:
-                b = self._operand(node.right, channels, in_hist)
-                c = self._control(node.mix, 'mix') if isinstance(node, fx.Mix) else None
-            ctl = c if isinstance(node, fx.Mix) else (b if isinstance(node, (fx.Gain, fx.Amp)) else None)
-            audio = [a] + ([b] if isinstance(node, (fx.Mix, fx.RingMod)) else [])
-            cols = broadcast_shape(*((1, t.shape[1]) for t in audio + ([ctl] if ctl is not None else [])))[1]
-            name = type(node).__name__
-            if all(t.shape[0] == 1 for t in audio) and not mod:
-                result = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)     # every operand is a one-row reply
-                o._launch(f'elementwise[{name}]', lambda: _native.elementwise(name, a, b, c, result), units=cols)
-            else:
-                result = torch.empty((rows, cols), dtype=AUDIO_DTYPE, device=dev)
-                main = result[hist:] if mod else result
-                o._launch(f'elementwise[{name}{",per-block" if mod else ""}]',
-                          lambda: _native.elementwise(name, a, b, c, main), units=main.shape[0] * cols)
-                if mod:
-                    self._own_history(node, cols, hist, result)
-
-        elif isinstance(node, ext.SumBus):
-            src_port, gains = node.input, node.resident_gains()
-            top = node.input.sig
-            if (o.fuse and isinstance(top, fx.Gain) and top.get_state().enabled and _ctl_const(top.right)
-                    and len(top.outputs_with_ports) == 1 and top.left.sig is not None):
-                # a per-voice Gain feeding only this bus is a diagonal scaling of the mix weights:
-                # sum_v pan[c,v] * (g[v] * x[n,v]) = sum_v (pan[c,v] * g[v]) * x[n,v]  -- fold it, skip the launch
-                g = self._control_const(top.right, 'right')
-                voices = top.left.channels
-                if g.shape[1] in (1, voices) and (gains is None or gains.shape[1] == voices):
-                    gains = (gains * g) if gains is not None else g.expand(1, voices).contiguous()
-                    src_port = top.left
-                    self._require(src_port.sig, voices, hist)
-            x = self._operand(src_port, src_port.channels, hist)
-            if x.shape[0] == 1:
-                raise NotBatchable('SumBus over a one-row input')
-            result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=dev)
-            o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
-
-        elif isinstance(node, ext.Tap):
-            self._memo[key] = self._materialise(node.input.sig, channels)      # pass-through: same buffer
-            return self._memo[key]
-
-        elif isinstance(node, files.FileWriter):
-            full, have = self._materialise(node.input.sig, channels)           # pass-through + record the batch
-            if full.shape[0] > 1:
-                node.write_rows(self.pos, self.rate, channels, full[have:])
-            self._memo[key] = (full, have)
-            return self._memo[key]
-
-        elif isinstance(node, files.FileReader):
-            result = node.read_rows(self.pos - hist, rows, self.rate, channels)
-            if result.shape[0] != rows:
-                raise NotBatchable('FileReader ran past the end of the file inside a batch')
-
-        elif isinstance(node, ext.ADSR):
-            ctl = node.control_rows(lambda bound: self._control_const(bound, bound.name))
-            _, voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))
-            result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=dev)
-            start = self.pos - hist
-            o._launch('adsr', lambda: _native.adsr(start, self.rate, ctl, result), units=rows * voices)
-
-        elif isinstance(node, ext.MixMatrix):
-            x = self._operand(node.input, channels, hist)
-            if x.shape[0] == 1 or x.shape[1] % 64:
-                raise ValueError(f'MixMatrix needs (rows, 64*g) audio, got {tuple(x.shape)}')
-            if x.dtype != AUDIO_DTYPE or not x.is_contiguous():
-                x = x.to(AUDIO_DTYPE).contiguous()
-            matrix = node.resident_matrix()
-            result = torch.empty_like(x)
-            o._launch('mix_matrix', lambda: _native.mix_matrix(x, matrix, result), units=x.shape[0] * x.shape[1])
-
-        elif isinstance(node, shape.Merge):
-            left = self._operand(node.left, node.left.channels, hist)
-            right = self._operand(node.right, node.right.channels, hist)
-            if left.shape[0] != right.shape[0]:
-                raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
-            result = torch.cat((left.to(AUDIO_DTYPE), right.to(AUDIO_DTYPE)), dim=1)
-
-        else:
-            raise NotBatchable(f'no batched schedule for {node.cls_name()}')
-
+                raise NotBatchable(f'no batched schedule for {node.cls_name()}')
+        if isinstance(result, tuple):                                          # a pass-through shares its input's buffer
+            self._memo[key] = result
+            return result
         if not _is_pure(node, self._pure) and result.shape[0] > 1:
             self._impure[node] = result
         self._memo[key] = (result, hist if result.shape[0] > 1 else 0)
@@ -509,138 +395,141 @@ class _Batch:
             return full
         return full[have - hist:] if have != hist else full
 
-    # -------------------------------------------------------------- fusion
-    def _try_fuse(self, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
-        """[SumBus(] [Gain(] LowPass|HighPass(Osc) [)] [)] -> one launch, when nothing else reads the
-        intermediates.  The chain form also serves a consumer that needs history rows (a second filter): the
-        launch writes the K blocks and the `hist` rows in front come from the tail / a fresh block like any
-        filter's.  None when the pattern does not apply."""
-        bus_node, top = None, node
-        if isinstance(node, ext.SumBus):
-            if not self.owner.fuse_bus or hist != 0:
-                return None
-            bus_node, top = node, node.input.sig
-            if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
-                return None
-            if node.channels not in (1, 2, 4):
-                return None
-            channels = node.input.channels
-        gain_node, filt = None, top
-        if isinstance(top, fx.Gain):
-            gain_node, filt = top, top.left.sig
-            if not isinstance(filt, fx.SingleCritFilter) or len(filt.outputs_with_ports) != 1:
-                return None
-        if not isinstance(filt, fx.SingleCritFilter) or not filt.get_state().enabled:
-            return None
-        src = filt.input.sig
-        if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
-            return None
-        ports = [src.hertz, src.phase, filt.cutoff] + ([gain_node.right] if gain_node is not None else [])
-        involved = [n for n in (src, filt, gain_node, bus_node) if n is not None]
+    # -------------------------------------------------------------- one schedule per node family
+    def _sched_fixed(self, node, channels, hist, rows):
+        value = node.resident()
+        if value.shape[0] != 1:
+            raise NotBatchable('multi-row Fixed as an audio source')
+        return value
 
-        def resolve():
-            """control rows as they are NOW (a Fixed re-uploads when its array changed); None if the pattern broke"""
-            if not all(n.get_state().enabled for n in involved):
-                return None
-            try:
-                rows_ = [self._control_const(p, p.name) for p in ports]
-            except NotBatchable:
-                return None
-            return rows_ + [None] * (4 - len(rows_))
-
-        resolved = resolve()
-        if resolved is None:
-            return None
-        hertz, phase, cutoff, gain = resolved
-        widths_ok = (max(hertz.shape[1], phase.shape[1]) == channels and cutoff.shape[1] == channels
-                     and hertz.shape[1] in (1, channels) and phase.shape[1] in (1, channels)
-                     and (gain is None or gain.shape[1] in (1, channels)))
-        if not widths_ok:
-            return None
+    def _sched_osc(self, node, channels, hist, rows):
         o = self.owner
-        rows = self.N * self.K
-        status = o._status_word(filt)
-        kind, btype = src.kind(), str(filt.type())
-        tag = f'{kind},{btype}{",gain" if gain is not None else ""}'
-        if bus_node is not None:
-            pan = bus_node.resident_gains()
-            if pan is not None and pan.shape[1] != channels:
-                return None
-            result = torch.empty((rows, bus_node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
-            need = _native.lib().sig_fused_voice_bus_workspace(channels, rows, bus_node.channels) // 8
-            if o._workspace is None or o._workspace.numel() < need:
-                o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
-            N, K, rate, bus_c, dev = self.N, self.K, self.rate, bus_node.channels, runtime.device()
-            # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs
-            # as a time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
-            small = channels * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS
-
-            def launch_bus(position: int, out: torch.Tensor | None = None) -> torch.Tensor:
-                ctl = resolve()
-                pan_now = bus_node.resident_gains()
-                if ctl is None or any(a.shape != b.shape for a, b in zip(ctl[:3], (hertz, phase, cutoff))) or \
-                        (pan_now is None) != (pan is None):
-                    o._replay = None
-                    return o.render(position, N, K)                  # pattern no longer holds: re-plan
-                if small and o.graph_replay and out is None:
-                    keys = tuple(t.data_ptr() if t is not None else 0 for t in (*ctl, pan_now))
-                    cap = o._captured
-                    if cap is None or cap.keys != keys:
-                        def record(pos_t: torch.Tensor) -> torch.Tensor:
-                            vbuf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
-                            bus_out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
-                            _native.fused_osc_biquad(kind, btype, rate, pos_t, N, K, CONTEXT,
-                                                     ctl[0], ctl[1], ctl[2], ctl[3], vbuf, status=status)
-                            return _native.sum_bus(vbuf, pan_now, bus_out)
-                        try:
-                            cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
-                        except RuntimeError:
-                            # capture refused (another capture in progress, a profiler that forbids it ...):
-                            # keep rendering with plain launches
-                            o.graph_replay, o._captured, cap = False, None, None
-                    if cap is not None:
-                        return cap.run(position)
-                out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev) if out is None else out
-                if small:
-                    voices_buf = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev)
-                    o._launch(f'fused_osc_biquad[{tag}]',
-                              lambda: _native.fused_osc_biquad(kind, btype, rate, position, N, K, CONTEXT,
-                                                               ctl[0], ctl[1], ctl[2], ctl[3], voices_buf, status=status),
-                              units=rows * channels)
-                    return o._launch('sum_bus', lambda: _native.sum_bus(voices_buf, pan_now, out), units=rows * channels)
-                return o._launch(f'fused_voice_bus[{tag}]',
-                                 lambda: _native.fused_voice_bus(kind, btype, rate, position, N, K, CONTEXT, channels,
-                                                                 ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
-                                                                 workspace=o._workspace, status=status),
-                                 units=rows * channels)
-            if node is o.node:
-                o._remember_replay(N, K, launch_bus)
-            return launch_bus(self.pos, result)
-        N, K, rate, dev = self.N, self.K, self.rate, runtime.device()
-
-        if hist:
-            result = torch.empty((hist + rows, channels), dtype=AUDIO_DTYPE, device=dev)
+        hertz = self._control(node.hertz, 'hertz')
+        phase = self._control(node.phase, 'phase')
+        _, voices = broadcast_shape((1, 1), (1, hertz.shape[1]), (1, phase.shape[1]))
+        result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=runtime.device())
+        if _modulated(node):
+            # hertz / phase are re-read every block: K parameter rows, N output rows each
             main = result[hist:]
-            o._launch(f'fused_osc_biquad[{tag}]',
-                      lambda: _native.fused_osc_biquad(kind, btype, rate, self.pos, N, K, CONTEXT,
-                                                       hertz, phase, cutoff, gain, main, status=status),
-                      units=rows * channels)
-            self._own_history(node, channels, hist, result)
-            return result
+            o._launch(f'osc_bank[{node.kind()},per-block]',
+                      lambda: _native.osc_bank(node.kind(), self.pos, self.rate, hertz, phase, main,
+                                               rows_per_param=self.N),
+                      units=main.shape[0] * voices)
+            self._own_history(node, voices, hist, result)
+        else:
+            start = self.pos - hist
+            o._launch(f'osc_bank[{node.kind()}]',
+                      lambda: _native.osc_bank(node.kind(), start, self.rate, hertz, phase, result),
+                      units=rows * voices)
+        return result
 
-        def launch_chain(position: int, out: torch.Tensor | None = None) -> torch.Tensor:
-            ctl = resolve()
-            if ctl is None or any(a.shape != b.shape for a, b in zip(ctl[:3], (hertz, phase, cutoff))):
-                o._replay = None
-                return o.render(position, N, K)
-            out = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=dev) if out is None else out
-            return o._launch(f'fused_osc_biquad[{tag}]',
-                             lambda: _native.fused_osc_biquad(kind, btype, rate, position, N, K, CONTEXT,
-                                                              ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
-                             units=rows * channels)
-        if node is o.node:
-            o._remember_replay(N, K, launch_chain)
-        return launch_chain(self.pos)
+    def _sched_noise(self, node, channels, hist, rows):
+        result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        seed, start = node.get_state().seed, self.pos - hist
+        return self.owner._launch('white_noise', lambda: _native.white_noise(seed, start, result), units=rows * channels)
+
+    def _sched_filter(self, node, channels, hist, rows):
+        return self._filter(node, channels, hist, rows)
+
+    def _sched_elementwise(self, node, channels, hist, rows):
+        o, dev = self.owner, runtime.device()
+        mod = _modulated(node)
+        in_hist = 0 if mod else hist                              # a modulated node's history comes from its tail
+        a = self._operand(node.left, channels, in_hist)
+        if isinstance(node, (fx.Gain, fx.Amp)):
+            b, c = self._control(node.right, 'right'), None
+        else:
+            b = self._operand(node.right, channels, in_hist)
+            c = self._control(node.mix, 'mix') if isinstance(node, fx.Mix) else None
+        ctl = c if isinstance(node, fx.Mix) else (b if isinstance(node, (fx.Gain, fx.Amp)) else None)
+        audio = [a] + ([b] if isinstance(node, (fx.Mix, fx.RingMod)) else [])
+        cols = broadcast_shape(*((1, t.shape[1]) for t in audio + ([ctl] if ctl is not None else [])))[1]
+        name = type(node).__name__
+        if all(t.shape[0] == 1 for t in audio) and not mod:
+            result = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)         # every operand is a one-row reply
+            return o._launch(f'elementwise[{name}]', lambda: _native.elementwise(name, a, b, c, result), units=cols)
+        result = torch.empty((rows, cols), dtype=AUDIO_DTYPE, device=dev)
+        main = result[hist:] if mod else result
+        o._launch(f'elementwise[{name}{",per-block" if mod else ""}]',
+                  lambda: _native.elementwise(name, a, b, c, main), units=main.shape[0] * cols)
+        if mod:
+            self._own_history(node, cols, hist, result)
+        return result
+
+    def _sched_bus(self, node, channels, hist, rows):
+        o = self.owner
+        src_port, gains = node.input, node.resident_gains()
+        top = node.input.sig
+        if (o.fuse and isinstance(top, fx.Gain) and top.get_state().enabled and _ctl_const(top.right)
+                and len(top.outputs_with_ports) == 1 and top.left.sig is not None):
+            # a per-voice Gain feeding only this bus is a diagonal scaling of the mix weights:
+            # sum_v pan[c,v] * (g[v] * x[n,v]) = sum_v (pan[c,v] * g[v]) * x[n,v]  -- fold it, skip the launch
+            g = self._control_const(top.right, 'right')
+            voices = top.left.channels
+            if g.shape[1] in (1, voices) and (gains is None or gains.shape[1] == voices):
+                gains = (gains * g) if gains is not None else g.expand(1, voices).contiguous()
+                src_port = top.left
+                self._require(src_port.sig, voices, hist)
+        x = self._operand(src_port, src_port.channels, hist)
+        if x.shape[0] == 1:
+            raise NotBatchable('SumBus over a one-row input')
+        result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        return o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+    def _sched_tap(self, node, channels, hist, rows):
+        return self._materialise(node.input.sig, channels)                    # pass-through: same buffer
+
+    def _sched_file_writer(self, node, channels, hist, rows):
+        full, have = self._materialise(node.input.sig, channels)              # pass-through + record the batch
+        if full.shape[0] > 1:
+            node.write_rows(self.pos, self.rate, channels, full[have:])
+        return full, have
+
+    def _sched_file_reader(self, node, channels, hist, rows):
+        result = node.read_rows(self.pos - hist, rows, self.rate, channels)
+        if result.shape[0] != rows:
+            raise NotBatchable('FileReader ran past the end of the file inside a batch')
+        return result
+
+    def _sched_adsr(self, node, channels, hist, rows):
+        ctl = node.control_rows(lambda bound: self._control_const(bound, bound.name))
+        _, voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))
+        result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=runtime.device())
+        start = self.pos - hist
+        return self.owner._launch('adsr', lambda: _native.adsr(start, self.rate, ctl, result), units=rows * voices)
+
+    def _sched_mix_matrix(self, node, channels, hist, rows):
+        x = self._operand(node.input, channels, hist)
+        if x.shape[0] == 1 or x.shape[1] % 64:
+            raise ValueError(f'MixMatrix needs (rows, 64*g) audio, got {tuple(x.shape)}')
+        if x.dtype != AUDIO_DTYPE or not x.is_contiguous():
+            x = x.to(AUDIO_DTYPE).contiguous()
+        matrix = node.resident_matrix()
+        result = torch.empty_like(x)
+        return self.owner._launch('mix_matrix', lambda: _native.mix_matrix(x, matrix, result),
+                                  units=x.shape[0] * x.shape[1])
+
+    def _sched_merge(self, node, channels, hist, rows):
+        left = self._operand(node.left, node.left.channels, hist)
+        right = self._operand(node.right, node.right.channels, hist)
+        if left.shape[0] != right.shape[0]:
+            raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
+        return torch.cat((left.to(AUDIO_DTYPE), right.to(AUDIO_DTYPE)), dim=1)     # buffer plumbing
+
+    _SCHEDULES = (
+        (fixed.Fixed, _sched_fixed),
+        (osc.Osc, _sched_osc),
+        (noise.White, _sched_noise),
+        (fx.CritFilter, _sched_filter),
+        ((fx.Mix, fx.RingMod, fx.Gain, fx.Amp), _sched_elementwise),
+        (ext.SumBus, _sched_bus),
+        (ext.Tap, _sched_tap),
+        (files.FileWriter, _sched_file_writer),
+        (files.FileReader, _sched_file_reader),
+        (ext.ADSR, _sched_adsr),
+        (ext.MixMatrix, _sched_mix_matrix),
+        (shape.Merge, _sched_merge),
+    )
 
     # -------------------------------------------------------------- filters
     def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:
@@ -704,3 +593,158 @@ class _Batch:
 
     def impure_outputs(self):
         return self._impure.items()
+
+
+class _VoiceChain:
+    """The fusable pattern  [SumBus(] [Gain(] LowPass|HighPass(Osc) [)] [)]  matched on a graph, when nothing else
+    consumes the intermediate nodes and every control input is block-invariant.  Launches it as
+    sig_fused_osc_biquad (chain) or sig_fused_voice_bus (chain + bus); in the latency regime the chain runs as a
+    prefix scan and the bus as its own launch, optionally captured into a hipGraph."""
+
+    def __init__(self, batch: _Batch, src, filt, gain_node, bus_node, channels: int):
+        self.batch, self.src, self.filt, self.gain_node, self.bus_node = batch, src, filt, gain_node, bus_node
+        self.channels = channels                                   # voices of the chain
+        self.ports = [src.hertz, src.phase, filt.cutoff] + ([gain_node.right] if gain_node is not None else [])
+        self.involved = [n for n in (src, filt, gain_node, bus_node) if n is not None]
+        self.kind, self.btype = src.kind(), str(filt.type())
+        self.tag = f'{self.kind},{self.btype}{",gain" if gain_node is not None else ""}'
+
+    # ---- matching
+    @classmethod
+    def match_and_launch(cls, batch: _Batch, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
+        bus_node, top = None, node
+        if isinstance(node, ext.SumBus):
+            if not batch.owner.fuse_bus or hist != 0 or node.channels not in (1, 2, 4):
+                return None
+            bus_node, top = node, node.input.sig
+            if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
+                return None
+            channels = node.input.channels
+        gain_node, filt = None, top
+        if isinstance(top, fx.Gain):
+            gain_node, filt = top, top.left.sig
+            if not isinstance(filt, fx.SingleCritFilter) or len(filt.outputs_with_ports) != 1:
+                return None
+        if not isinstance(filt, fx.SingleCritFilter) or not filt.get_state().enabled:
+            return None
+        src = filt.input.sig
+        if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
+            return None
+        chain = cls(batch, src, filt, gain_node, bus_node, channels)
+        controls = chain.resolve()
+        if controls is None or not chain.widths_ok(controls):
+            return None
+        return chain.launch_bus(node, controls) if bus_node is not None else chain.launch_chain(node, controls, hist)
+
+    def resolve(self):
+        """[hertz, phase, cutoff, gain|None] as they are NOW (a Fixed re-uploads when its array changed);
+        None if the pattern no longer holds"""
+        if not all(n.get_state().enabled for n in self.involved):
+            return None
+        try:
+            rows = [self.batch._control_const(p, p.name) for p in self.ports]
+        except NotBatchable:
+            return None
+        return rows + [None] * (4 - len(rows))
+
+    def widths_ok(self, controls) -> bool:
+        hertz, phase, cutoff, gain = controls
+        v = self.channels
+        return (max(hertz.shape[1], phase.shape[1]) == v and cutoff.shape[1] == v
+                and hertz.shape[1] in (1, v) and phase.shape[1] in (1, v) and (gain is None or gain.shape[1] in (1, v)))
+
+    def _same_shapes(self, now, then) -> bool:
+        return now is not None and all(a.shape == b.shape for a, b in zip(now[:3], then[:3]))
+
+    # ---- chain only: out (K*N, voices)
+    def launch_chain(self, node: Emitter, controls, hist: int) -> torch.Tensor:
+        b, o, dev = self.batch, self.batch.owner, runtime.device()
+        N, K, rate, v = b.N, b.K, b.rate, self.channels
+        rows = N * K
+        status = o._status_word(self.filt)
+        name = f'fused_osc_biquad[{self.tag}]'
+
+        def run(position, ctl, out):
+            return o._launch(name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
+                                                                    ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
+                             units=rows * v)
+        if hist:
+            # a consumer (a second filter) needs history rows: the launch writes the K blocks, the rows in front
+            # come from the tail / a fresh block like any filter's
+            result = torch.empty((hist + rows, v), dtype=AUDIO_DTYPE, device=dev)
+            run(b.pos, controls, result[hist:])
+            b._own_history(node, v, hist, result)
+            return result
+
+        def replay(position: int) -> torch.Tensor:
+            ctl = self.resolve()
+            if not self._same_shapes(ctl, controls):
+                o._replay = None
+                return o.render(position, N, K)                  # pattern no longer holds: re-plan
+            return run(position, ctl, torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev))
+        if node is o.node:
+            o._remember_replay(N, K, replay)
+        return run(b.pos, controls, torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev))
+
+    # ---- chain + bus: out (K*N, bus channels)
+    def launch_bus(self, node: Emitter, controls) -> torch.Tensor:
+        b, o, dev = self.batch, self.batch.owner, runtime.device()
+        N, K, rate, v = b.N, b.K, b.rate, self.channels
+        rows, bus_c = N * K, self.bus_node.channels
+        pan = self.bus_node.resident_gains()
+        if pan is not None and pan.shape[1] != v:
+            return None
+        status = o._status_word(self.filt)
+        need = _native.lib().sig_fused_voice_bus_workspace(v, rows, bus_c) // 8
+        if o._workspace is None or o._workspace.numel() < need:
+            o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=dev)
+        # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs as a
+        # time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
+        small = v * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS
+        chain_name, bus_name = f'fused_osc_biquad[{self.tag}]', f'fused_voice_bus[{self.tag}]'
+
+        def run(position, ctl, pan_now, out):
+            if small:
+                voices_buf = torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev)
+                o._launch(chain_name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
+                                                                       ctl[0], ctl[1], ctl[2], ctl[3], voices_buf,
+                                                                       status=status), units=rows * v)
+                return o._launch('sum_bus', lambda: _native.sum_bus(voices_buf, pan_now, out), units=rows * v)
+            return o._launch(bus_name, lambda: _native.fused_voice_bus(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
+                                                                       ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
+                                                                       workspace=o._workspace, status=status),
+                             units=rows * v)
+
+        def captured(position, ctl, pan_now):
+            """hipGraph of [scan chain(position on device) -> bus -> position += N*K]; None if capture is refused"""
+            keys = tuple(t.data_ptr() if t is not None else 0 for t in (*ctl, pan_now))
+            cap = o._captured
+            if cap is None or cap.keys != keys:
+                def record(pos_t: torch.Tensor) -> torch.Tensor:
+                    vbuf = torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev)
+                    bus_out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
+                    _native.fused_osc_biquad(self.kind, self.btype, rate, pos_t, N, K, CONTEXT,
+                                             ctl[0], ctl[1], ctl[2], ctl[3], vbuf, status=status)
+                    return _native.sum_bus(vbuf, pan_now, bus_out)
+                try:
+                    cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
+                except RuntimeError:
+                    # capture refused (another capture in progress, a profiler that forbids it ...):
+                    # keep rendering with plain launches
+                    o.graph_replay, o._captured = False, None
+                    return None
+            return cap.run(position)
+
+        def replay(position: int) -> torch.Tensor:
+            ctl, pan_now = self.resolve(), self.bus_node.resident_gains()
+            if not self._same_shapes(ctl, controls) or (pan_now is None) != (pan is None):
+                o._replay = None
+                return o.render(position, N, K)                  # pattern no longer holds: re-plan
+            if small and o.graph_replay:
+                out = captured(position, ctl, pan_now)
+                if out is not None:
+                    return out
+            return run(position, ctl, pan_now, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
+        if node is o.node:
+            o._remember_replay(N, K, replay)
+        return run(b.pos, controls, pan, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
