@@ -89,12 +89,16 @@ def cpu_baseline(p, voices, frames, budget_s=12.0):
     pan = p['pan'][:, sl]
     t0 = time.perf_counter()
     blocks = 0
+    kept = []                                   # the first blocks' stereo bus, for the max-abs-error leg
     while True:
-        R.sum_bus(R.render(node, blocks * frames, frames, voices, RATE), pan)
+        bus = R.sum_bus(R.render(node, blocks * frames, frames, voices, RATE), pan)
+        if blocks < 8:
+            kept.append(bus)
         blocks += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or blocks >= 64:
             break
+    cpu_baseline.reference_bus = np.concatenate(kept)
     return dict(value=voices * frames * blocks / dt / 1e6, unit='Msamples/s', cores=1, kind='port',
                 sample=f'{blocks} consecutive {frames}-frame blocks of the {voices}-voice C2 graph from position 0, '
                        f'{dt:.1f} s, oracle/chain_ref.py (numpy {np.__version__}, scipy butter+sosfilt per channel per block), '
@@ -314,6 +318,16 @@ def main():
             line['latency_mode'] = latency
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(params, V, N)
+            # BASELINE.json's second metric: max-abs sample error of the rendered bus against float32(oracle float64)
+            from signals_amd.engine import BatchRenderer
+            ref = cpu_baseline.reference_bus.astype(np.float32).astype(np.float64)
+            nb = ref.shape[0] // N
+            errs = {}
+            for label, fuse in (('fused', True), ('materialised', False)):
+                got = BatchRenderer(build_graph(params, 0, V), 2, RATE, fuse=fuse).render(0, N, nb).double().cpu().numpy()
+                errs[label] = float(np.max(np.abs(got - ref)))
+            line['max_abs_error'] = dict(errs, bar=1e-6, full_scale=float(np.max(np.abs(ref))),
+                                         sample=f'stereo bus of the first {nb} blocks of the {V}-voice graph vs the CPU oracle')
             workers = min(16, os.cpu_count() or 1)                      # the GPU box's CPU share for one GPU
             if workers > 1 and V % workers == 0:
                 line['cpu_baseline_sharded'] = cpu_baseline_sharded(params, V, N, workers)
