@@ -144,6 +144,12 @@ int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices,
              const double* const* params, const int32_t* strides,
              void* out, int32_t out_dtype, int64_t out_ld, void* stream);
 
+/* out = ADSR envelope * x in one pass: the RingMod(x, ADSR) pair (fx.py:43-46 over the envelope of sig_adsr) without
+ * storing the envelope -- 8 B per voice-sample instead of 16.  f32 in / f32 out, product formed in f64. */
+int sig_adsr_apply(int64_t position, int32_t rate, int64_t rows, int32_t voices,
+                   const double* const* params, const int32_t* strides,
+                   const float* x, int64_t x_ld, float* out, int64_t out_ld, void* stream);
+
 /* Build-defined dense mix matrix (BASELINE config 5), f32 in/out, exact-f32 MFMA
  * (v_mfma_f32_32x32x2_f32):  out[n, 64g:64g+64] = x[n, 64g:64g+64] @ matrix,  matrix (64,64)
  * row-major contiguous, voices % 64 == 0, x 16-byte aligned with x_ld % 4 == 0. */

@@ -21,7 +21,7 @@ STATUS_BAD_CUTOFF = 1
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
-           'sig_fused_osc_biquad_devpos', 'sig_advance_position')
+           'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply')
 
 
 class NativeError(RuntimeError):
@@ -80,6 +80,9 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_osc_biquad_devpos.restype = ctypes.c_int
         L.sig_fused_osc_biquad_devpos.argtypes = [ctypes.c_int, ctypes.c_int, i32, vp, i32, i32, i32, i32,
                                                   dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
+        L.sig_adsr_apply.restype = ctypes.c_int
+        L.sig_adsr_apply.argtypes = [i64, i32, i64, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                                     vp, i64, vp, i64, vp]
         L.sig_advance_position.restype = ctypes.c_int
         L.sig_advance_position.argtypes = [vp, i64, vp]
         if L.sig_abi_version() != 2:
@@ -364,4 +367,22 @@ def band_coldstart(btype: str, rate: int, position: int, block_frames: int, nblo
                                     in_ptr, buf.stride(0), history, out.data_ptr(), out.stride(0), _dt(out),
                                     status.data_ptr() if status is not None else None, _stream(out)),
            'sig_band_coldstart')
+    return out
+
+
+def adsr_apply(position: int, rate: int, rows: dict, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out = ADSR(rows) * x, float32, one pass"""
+    _gpu(x, out, *rows.values())
+    _audio(x, 'adsr_apply in')
+    _audio(out, 'adsr_apply out')
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or x.shape != out.shape:
+        raise NativeError(f'adsr_apply is float32 (rows, V) in and out, got {tuple(x.shape)} {x.dtype} -> {tuple(out.shape)} {out.dtype}')
+    ptrs = (ctypes.c_void_p * 6)()
+    strides = (ctypes.c_int32 * 6)()
+    for i, name in enumerate(ADSR_PARAMS):
+        ptrs[i], strides[i] = _ctrl_row(rows[name], name)
+        if rows[name].shape[1] not in (1, out.shape[1]):
+            raise NativeError(f'{name} has {rows[name].shape[1]} channels for {out.shape[1]} voices')
+    _check(lib().sig_adsr_apply(position, rate, out.shape[0], out.shape[1], ptrs, strides, x.data_ptr(), x.stride(0),
+                                out.data_ptr(), out.stride(0), _stream(out)), 'sig_adsr_apply')
     return out

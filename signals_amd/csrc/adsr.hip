@@ -28,9 +28,12 @@ __device__ __forceinline__ double held(const Voice& p, double t) {
 
 constexpr int kRowsPerWave = 16;
 
-template <int VEC, typename OUT>
+// MUL: out = envelope * x (the RingMod(x, ADSR) pair of BASELINE config 3 in one pass: 8 B per voice-sample
+// instead of 4 (envelope store) + 12 (RingMod)); x is f32 audio aligned with `out`.
+template <int VEC, typename OUT, bool MUL>
 __global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate, int64_t rows, int voices, AdsrRows in,
-                                                   OUT* __restrict__ out, int64_t ld, int voice_tiles)
+                                                   OUT* __restrict__ out, int64_t ld, int voice_tiles,
+                                                   const float* __restrict__ x, int64_t x_ld)
 {
     const int lane = threadIdx.x & 63;
     const int vt = blockIdx.x % voice_tiles;
@@ -60,11 +63,21 @@ __global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate
         if (row >= rows) break;
         const double t = sig_readlane_f64(q_lane, j);
         OUT y[VEC];
+        float xin[VEC];
+        if (MUL) {
+            if (VEC == 4) {
+                const float4 v = (v0 < voices) ? *reinterpret_cast<const float4*>(x + row * x_ld + v0) : make_float4(0, 0, 0, 0);
+                xin[0] = v.x; xin[1 % VEC] = v.y; xin[2 % VEC] = v.z; xin[3 % VEC] = v.w;
+            } else {
+                xin[0] = (v0 < voices) ? x[row * x_ld + v0] : 0.0f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const double w = t - p[i].off;
             const double rel = (p[i].ir > 0.0) ? clip01(1.0 - w * p[i].ir) : 0.0;
-            y[i] = (OUT)((w < 0.0) ? held(p[i], t) : p[i].hold_off * rel);
+            const double env = (w < 0.0) ? held(p[i], t) : p[i].hold_off * rel;
+            y[i] = (OUT)(MUL ? env * (double)xin[i] : env);
         }
         OUT* dst = out + row * ld + v0;
         if (VEC == 4) {
@@ -81,15 +94,19 @@ __global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate
 
 template <typename OUT>
 int launch_adsr(int64_t position, int32_t rate, int64_t rows, int32_t voices, const AdsrRows& in, OUT* out, int64_t ld,
-                hipStream_t stream)
+                const float* x, int64_t x_ld, hipStream_t stream)
 {
-    const bool vec4 = (voices % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(OUT)) == 0);
+    const bool vec4 = (voices % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % (4 * sizeof(OUT)) == 0) &&
+                      (!x || (x_ld % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0));
     const int span = SIG_WAVE * (vec4 ? 4 : 1);
     const int voice_tiles = (voices + span - 1) / span;
     const int64_t nwg = ((rows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave)) * voice_tiles;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    if (vec4) adsr_kernel<4, OUT><<<(unsigned)nwg, 256, 0, stream>>>(position, (double)rate, rows, voices, in, out, ld, voice_tiles);
-    else adsr_kernel<1, OUT><<<(unsigned)nwg, 256, 0, stream>>>(position, (double)rate, rows, voices, in, out, ld, voice_tiles);
+#define SIG_ADSR(V, M) adsr_kernel<V, OUT, M><<<(unsigned)nwg, 256, 0, stream>>>(position, (double)rate, rows, voices, in, \
+                                                                                    out, ld, voice_tiles, x, x_ld)
+    if (vec4) { if (x) SIG_ADSR(4, true); else SIG_ADSR(4, false); }
+    else      { if (x) SIG_ADSR(1, true); else SIG_ADSR(1, false); }
+#undef SIG_ADSR
     return sig_launch_status();
 }
 
@@ -108,7 +125,23 @@ extern "C" int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t vo
     }
     if (rows == 0 || voices == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (out_dtype == SIG_F32) return launch_adsr<float>(position, rate, rows, voices, in, static_cast<float*>(out), out_ld, s);
-    if (out_dtype == SIG_F64) return launch_adsr<double>(position, rate, rows, voices, in, static_cast<double*>(out), out_ld, s);
+    if (out_dtype == SIG_F32) return launch_adsr<float>(position, rate, rows, voices, in, static_cast<float*>(out), out_ld, nullptr, 0, s);
+    if (out_dtype == SIG_F64) return launch_adsr<double>(position, rate, rows, voices, in, static_cast<double*>(out), out_ld, nullptr, 0, s);
     return (int)hipErrorInvalidValue;
+}
+
+extern "C" int sig_adsr_apply(int64_t position, int32_t rate, int64_t rows, int32_t voices,
+                              const double* const* params, const int32_t* strides,
+                              const float* x, int64_t x_ld, float* out, int64_t out_ld, void* stream)
+{
+    SIG_CHECK_ARG(position >= 0 && rate > 0 && rows >= 0 && voices >= 0 && params && strides && x && out);
+    SIG_CHECK_ARG(out_ld >= voices && x_ld >= voices);
+    AdsrRows in;
+    for (int i = 0; i < 6; ++i) {
+        SIG_CHECK_ARG(params[i] != nullptr && (strides[i] == 0 || strides[i] == 1));
+        in.p[i] = params[i];
+        in.s[i] = strides[i];
+    }
+    if (rows == 0 || voices == 0) return 0;
+    return launch_adsr<float>(position, rate, rows, voices, in, out, out_ld, x, x_ld, static_cast<hipStream_t>(stream));
 }

@@ -433,6 +433,10 @@ class _Batch:
 
     def _sched_elementwise(self, node, channels, hist, rows):
         o, dev = self.owner, runtime.device()
+        if o.fuse and isinstance(node, fx.RingMod):
+            enveloped = self._ringmod_with_envelope(node, channels, hist, rows)
+            if enveloped is not None:
+                return enveloped
         mod = _modulated(node)
         in_hist = 0 if mod else hist                              # a modulated node's history comes from its tail
         a = self._operand(node.left, channels, in_hist)
@@ -455,6 +459,23 @@ class _Batch:
         if mod:
             self._own_history(node, cols, hist, result)
         return result
+
+    def _ringmod_with_envelope(self, node, channels, hist, rows):
+        """RingMod(x, ADSR) with an envelope nobody else reads: envelope * x in one pass (sig_adsr_apply)"""
+        for env_port, x_port in ((node.right, node.left), (node.left, node.right)):
+            env = env_port.sig
+            if (isinstance(env, ext.ADSR) and env.get_state().enabled and len(env.outputs_with_ports) == 1
+                    and not _modulated(env) and x_port.sig is not None and not isinstance(x_port.sig, ext.ADSR)):
+                x = self._operand(x_port, channels, hist)
+                ctl = env.control_rows(lambda bound: self._control_const(bound, bound.name))
+                voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))[1]
+                if x.shape[0] == 1 or x.shape[1] != voices or x.dtype != AUDIO_DTYPE:
+                    return None
+                result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=runtime.device())
+                start = self.pos - hist
+                return self.owner._launch('adsr_apply', lambda: _native.adsr_apply(start, self.rate, ctl, x, result),
+                                          units=rows * voices)
+        return None
 
     def _sched_bus(self, node, channels, hist, rows):
         o = self.owner

@@ -562,3 +562,21 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
     e = BlockDriver(); e.input = build(hz)[0]
     pulled = np.concatenate([d.pull() for _ in range(6)])
     assert maxerr(pulled, np.concatenate([e.pull(eager=True) for _ in range(6)])) < 1e-7
+
+
+def test_ringmod_with_adsr_in_one_pass():
+    """RingMod(x, ADSR) -> sig_adsr_apply when the envelope has no other consumer; C3 stays within 1e-6 of the oracle"""
+    from oracle import chain_ref as R
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N, K = 16, 1024, 3
+    bus, p = c3_graph(V)
+    timer = KernelTimer()
+    got = BatchRenderer(bus, 1, RATE, timer=timer).render(0, N, K).cpu().numpy()
+    torch.cuda.synchronize()
+    names = set(timer.summary())
+    assert 'adsr_apply' in names and 'adsr' not in names and not any(n.startswith('elementwise[RingMod') for n in names), names
+    o = R.Osc('Sawtooth', R.Fixed(p['hertz']), R.Fixed(p['phase']))
+    f2 = R.Filter('lp', R.Filter('lp', o, R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
+    ref = R.sum_bus(R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, K, V))
+    assert maxerr(got, f32(ref)) < 1e-6
+    assert maxerr(got, batched(c3_graph(V)[0], 0, N, K, 1)) < 1e-6
