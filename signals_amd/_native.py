@@ -10,7 +10,10 @@ import pathlib
 
 import torch
 
-LIB_PATH = pathlib.Path(__file__).resolve().parent / 'csrc' / 'libsignals_amd.so'
+import os
+
+# SIG_LIB_PATH: load another build of the same ABI (kernel tuning A/B runs only)
+LIB_PATH = pathlib.Path(os.environ.get('SIG_LIB_PATH') or pathlib.Path(__file__).resolve().parent / 'csrc' / 'libsignals_amd.so')
 
 F32, F64 = 0, 1
 OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}

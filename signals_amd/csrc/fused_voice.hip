@@ -33,7 +33,10 @@ __device__ __forceinline__ void put(float& v, const float (&y)[1]) { v = y[0]; }
 __device__ __forceinline__ void put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
 __device__ __forceinline__ void put(float4& v, const float (&y)[4]) { v = make_float4(y[0], y[1], y[2], y[3]); }
 
-constexpr int kIlp = 4;     // rows whose oscillator samples are computed ahead of the recurrence
+#ifndef SIG_FUSED_ILP
+#define SIG_FUSED_ILP 4
+#endif
+constexpr int kIlp = SIG_FUSED_ILP;     // rows whose oscillator samples are computed ahead of the recurrence
 
 struct FusedArgs {
     int type; double rate; int64_t position; int N, K, ctx, voices;
