@@ -133,3 +133,28 @@ def test_c4_eight_shards_of_1024_voices_sum_to_the_unsharded_bus():
         acc += BatchRenderer(bench.build_graph(p, lo, hi), 2, RATE).render(0, N, k).double()
     assert float((acc - whole).abs().max()) < 1e-7          # summation order differs: rounding-level agreement
     assert float(whole.abs().max()) > 1e-4
+
+
+def test_one_hour_stream_stays_finite_and_position_pure(params):
+    """render a whole hour of the 1024-voice graph in 1024-block batches (172.8 M frames, 177 G voice-samples);
+    every batch finite, and blocks met in-stream equal the same blocks rendered from a cold renderer"""
+    from signals_amd.engine import BatchRenderer
+    k = 1024
+    r = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE)
+    pos, checks, peak = 0, {}, 0.0
+    probe_at = {0, 300, 659}
+    for step in range(660):                                   # 660 * 262144 frames = 60.08 min
+        bus = r.render(pos, N, k)
+        if step % 60 == 0 or step in probe_at:
+            assert bool(torch.isfinite(bus).all()), step
+            peak = max(peak, float(bus.abs().max()))
+        if step in probe_at:
+            checks[pos] = bus[:4 * N].clone()
+        pos += N * k
+    assert pos >= 172_800_000 and 1e-3 < peak < 1.0
+    for p0, want in checks.items():
+        cold = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE)
+        cold.scan_max_chains = 0                              # same (serial, bus-fused) kernel as the big batches
+        assert torch.equal(cold.render(p0, N, 4), want), p0
+        latency = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE).render(p0, N, 4)      # scan chain + bus launch
+        assert float((latency.double() - want.double()).abs().max()) < 1e-8, p0
