@@ -110,3 +110,22 @@ if __name__ == '__main__' and os.environ.get('TUNE') == 'walk':
     for K in (256, 1024):
         ms, gbs = time_biquad(K)
         print(f'walk={os.environ.get("SIG_BIQUAD_WALK","auto")} K={K}: {ms*1e3:.1f} us  {gbs:.0f} GB/s algorithmic', flush=True)
+
+
+def time_gain(K, reps=20):
+    x = torch.rand((K * N, V), device='cuda') * 2 - 1
+    g = torch.tensor(np.random.default_rng(0).uniform(0, 1, (1, V)), device='cuda')
+    out = torch.empty_like(x)
+    for _ in range(3): _native.elementwise('Gain', x, g, None, out)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): _native.elementwise('Gain', x, g, None, out)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    return ms, 8 * K * N * V / ms / 1e6
+
+if __name__ == '__main__' and os.environ.get('TUNE') == 'gain':
+    for K in (256, 1024):
+        ms, gbs = time_gain(K)
+        print(f'gain K={K}: {ms*1e3:.1f} us {gbs:.0f} GB/s', flush=True)
