@@ -16,3 +16,7 @@ done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libsignals_amd.so "${OBJS[@]}"
 echo "built $(pwd)/libsignals_amd.so"
+# torch-free example of the C ABI (examples/c2_direct.cpp); tests/test_abi_direct.py runs it on the GPU box
+$HIPCC --offload-arch=gfx950 -O2 -I ../../include ../../examples/c2_direct.cpp -L . -lsignals_amd \
+    -Wl,-rpath,'$ORIGIN/../signals_amd/csrc' -o ../../examples/c2_direct 2>/dev/null
+echo "built $(cd ../../examples && pwd)/c2_direct"
