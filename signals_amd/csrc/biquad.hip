@@ -218,24 +218,36 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
                (reinterpret_cast<uintptr_t>(out) % (vpt * sizeof(T)) == 0);
     };
     int variant = biquad_variant();
-    // span walker: every row read once (see biquad_walk_kernel).  Keep >= ~2048 waves on the chip.
+    // span walker: every row read once (see biquad_walk_kernel).  Keep >= ~1024 waves on the chip.
     {
         static const int walk_env = [] { const char* e = getenv("SIG_BIQUAD_WALK"); return e ? atoi(e) : -1; }();
-        const int wvpt = ok(2) ? 2 : 1;
+        static const int walk_variant = [] { const char* e = getenv("SIG_WALK_VARIANT"); return e ? atoi(e) : 0; }();
+        int wvpt = walk_variant ? walk_variant / 100 : 4;                     // tuning: <vpt><ring>, e.g. 216
+        const int wring = walk_variant ? walk_variant % 100 : 16;
+        while (wvpt > 1 && !ok(wvpt)) wvpt >>= 1;
         const int tiles = (voices + SIG_WAVE * wvpt - 1) / (SIG_WAVE * wvpt);
-        int span = (int)(((int64_t)tiles * K) / 2048);
-        if (span > 8) span = 8;
+        // measured on C2 at K=1024 (vpt x ring x span sweep): 4 voices/lane, 16 rows in flight, span 4 is the best
+        // point (5.0 TB/s algorithmic); longer spans starve the chip of waves, shorter ones re-read more context
+        int span = (int)(((int64_t)tiles * K) / 1024);
+        if (span > 4) span = 4;
         if (walk_env >= 0) span = walk_env;                                    // tuning: 0/1 disables
         if (span >= 2 && N > ctx && cutoff_blocks == 1 && variant == 0) {
             const int64_t items = (int64_t)tiles * ((K + span - 1) / span);
             const int64_t nwg = (items + 3) / 4;
             if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-            if (wvpt == 2)
-                biquad_walk_kernel<T, 2, 16><<<(unsigned)nwg, 256, 0, stream>>>(
-                    type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status);
-            else
-                biquad_walk_kernel<T, 1, 16><<<(unsigned)nwg, 256, 0, stream>>>(
-                    type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status);
+#define SIG_WALK(V, R) biquad_walk_kernel<T, V, R><<<(unsigned)nwg, 256, 0, stream>>>( \
+                type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status)
+            switch (wvpt * 100 + wring) {
+                case 116: SIG_WALK(1, 16); break;
+                case 132: SIG_WALK(1, 32); break;
+                case 216: SIG_WALK(2, 16); break;
+                case 232: SIG_WALK(2, 32); break;
+                case 408: SIG_WALK(4, 8); break;
+                case 416: SIG_WALK(4, 16); break;
+                case 432: SIG_WALK(4, 32); break;
+                default: return (int)hipErrorInvalidValue;
+            }
+#undef SIG_WALK
             return sig_launch_status();
         }
     }
