@@ -87,6 +87,16 @@ int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
                          void* out, int64_t out_ld, int32_t dtype,
                          int32_t* status, void* stream);
 
+/* sig_biquad_coldstart whose stored rows are multiplied by a per-voice ADSR envelope evaluated at the row's
+ * time (f32 buffers): RingMod(Filter(x), ADSR) -- fx.py:43-46 over fx.py:85-121 and the envelope of sig_adsr --
+ * without the envelope store and the extra read/write pass.  adsr_params / adsr_strides as in sig_adsr. */
+int sig_biquad_coldstart_env(int type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                             const double* const* adsr_params, const int32_t* adsr_strides,
+                             const float* in, int64_t in_ld, int64_t in_history,
+                             float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* BandPass / BandStop done right (the reference's DoubleCritFilter raises TypeError at
  * fx.py:99, its intent being butter(N=2, Wn=[low, high], btype='bp'|'bs', output='sos') + sosfilt):
  * two biquad sections in series, designed in closed form per voice, same cold-start block semantics and

@@ -24,7 +24,7 @@ STATUS_BAD_CUTOFF = 1
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
-           'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply')
+           'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env')
 
 
 class NativeError(RuntimeError):
@@ -86,6 +86,10 @@ def lib() -> ctypes.CDLL:
         L.sig_adsr_apply.restype = ctypes.c_int
         L.sig_adsr_apply.argtypes = [i64, i32, i64, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
                                      vp, i64, vp, i64, vp]
+        L.sig_biquad_coldstart_env.restype = ctypes.c_int
+        L.sig_biquad_coldstart_env.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, i32,
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                                               vp, i64, i64, vp, i64, vp, vp]
         L.sig_advance_position.restype = ctypes.c_int
         L.sig_advance_position.argtypes = [vp, i64, vp]
         if L.sig_abi_version() != 2:
@@ -174,11 +178,12 @@ def osc_bank(kind: str, position: int, rate: int, hertz: torch.Tensor, phase: to
 
 def biquad_coldstart(btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
                      cutoff: torch.Tensor, buf: torch.Tensor, history: int, out: torch.Tensor,
-                     status: torch.Tensor | None = None) -> torch.Tensor:
+                     status: torch.Tensor | None = None, envelope: dict | None = None) -> torch.Tensor:
     """`buf` holds `history` context rows followed by nblocks*block_frames input rows;
     `out` (nblocks*block_frames, voices) receives the filtered blocks.
-    cutoff: f64 (1|nblocks, V|1)."""
-    _gpu(cutoff, buf, out, status)
+    cutoff: f64 (1|nblocks, V|1).  `envelope`: ADSR control rows (name -> (1,V)|(1,1) f64); the stored rows
+    are then multiplied by the envelope (float32 buffers only)."""
+    _gpu(cutoff, buf, out, status, *(envelope or {}).values())
     _audio(buf, 'biquad in')
     _audio(out, 'biquad out')
     rows, voices = out.shape
@@ -195,6 +200,21 @@ def biquad_coldstart(btype: str, rate: int, position: int, block_frames: int, nb
         # the reference indexes crit[0, i] for every channel i (fx.py:99)
         raise IndexError(f'index {cutoff.shape[1]} is out of bounds for axis 1 with size {cutoff.shape[1]}')
     in_ptr = buf.data_ptr() + history * buf.stride(0) * buf.element_size()
+    if envelope is not None:
+        if out.dtype != torch.float32:
+            raise NativeError('the envelope epilogue is float32 only')
+        ptrs = (ctypes.c_void_p * 6)()
+        strides = (ctypes.c_int32 * 6)()
+        for i, name in enumerate(ADSR_PARAMS):
+            ptrs[i], strides[i] = _ctrl_row(envelope[name], name)
+            if envelope[name].shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {envelope[name].shape[1]} channels for {voices} voices')
+        _check(lib().sig_biquad_coldstart_env(FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
+                                              cutoff.data_ptr(), 0 if cutoff.shape[1] == 1 else 1, cutoff.shape[0],
+                                              ptrs, strides, in_ptr, buf.stride(0), history, out.data_ptr(), out.stride(0),
+                                              status.data_ptr() if status is not None else None, _stream(out)),
+               'sig_biquad_coldstart_env')
+        return out
     _check(lib().sig_biquad_coldstart(FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
                                       cutoff.data_ptr(), 0 if cutoff.shape[1] == 1 else 1, cutoff.shape[0],
                                       in_ptr, buf.stride(0), history, out.data_ptr(), out.stride(0), _dt(out),

@@ -8,23 +8,11 @@
 //            = held(gate_off) * clip(1 - w * (1/release), 0, 1)  (release == 0: 0)
 // Definition and operator order are those of oracle/chain_ref.py:adsr (f64, contract off), so the f32 store
 // is bit-exact against it.  HBM-write-bound: 4 B per voice-sample, ~12 f64 ops.
-#include "sig_common.h"
+#include "sig_adsr.h"
 
 namespace {
 
-struct AdsrRows { const double* p[6]; int s[6]; };   // attack, decay, sustain, release, gate_on, gate_off
-
-__device__ __forceinline__ double clip01(double x) { return (x < 0.0) ? 0.0 : ((x > 1.0) ? 1.0 : x); }
-
-struct Voice { double ia, id, sm1, ir, on, off, attack, hold_off; };
-
-__device__ __forceinline__ double held(const Voice& p, double t) {
-    const double u = t - p.on;
-    const double v = u - p.attack;
-    const double a = (p.ia > 0.0) ? clip01(u * p.ia) : 1.0;
-    const double d = (p.id > 0.0) ? clip01(v * p.id) : 1.0;
-    return (u < 0.0) ? 0.0 : ((v < 0.0) ? a : 1.0 + p.sm1 * d);
-}
+using namespace sig_env;
 
 constexpr int kRowsPerWave = 16;
 
@@ -44,19 +32,7 @@ __global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate
     const double q_lane = (double)(position + r0 + (lane & (kRowsPerWave - 1))) / rate;
     Voice p[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        const int v = (v0 + i < voices) ? v0 + i : 0;
-        const double attack = in.p[0][(int64_t)v * in.s[0]], decay = in.p[1][(int64_t)v * in.s[1]];
-        const double sustain = in.p[2][(int64_t)v * in.s[2]], release = in.p[3][(int64_t)v * in.s[3]];
-        p[i].on = in.p[4][(int64_t)v * in.s[4]];
-        p[i].off = in.p[5][(int64_t)v * in.s[5]];
-        p[i].attack = attack;
-        p[i].ia = (attack > 0.0) ? 1.0 / attack : 0.0;
-        p[i].id = (decay > 0.0) ? 1.0 / decay : 0.0;
-        p[i].ir = (release > 0.0) ? 1.0 / release : 0.0;
-        p[i].sm1 = sustain - 1.0;
-        p[i].hold_off = held(p[i], p[i].off);
-    }
+    for (int i = 0; i < VEC; ++i) p[i] = load_voice(in, (v0 + i < voices) ? v0 + i : 0);
 #pragma unroll 2
     for (int j = 0; j < kRowsPerWave; ++j) {
         const int64_t row = r0 + j;
@@ -64,19 +40,15 @@ __global__ __launch_bounds__(256) void adsr_kernel(int64_t position, double rate
         const double t = sig_readlane_f64(q_lane, j);
         OUT y[VEC];
         float xin[VEC];
-        if (MUL) {
-            if (VEC == 4) {
-                const float4 v = (v0 < voices) ? *reinterpret_cast<const float4*>(x + row * x_ld + v0) : make_float4(0, 0, 0, 0);
-                xin[0] = v.x; xin[1 % VEC] = v.y; xin[2 % VEC] = v.z; xin[3 % VEC] = v.w;
-            } else {
-                xin[0] = (v0 < voices) ? x[row * x_ld + v0] : 0.0f;
-            }
+        if constexpr (MUL && VEC == 4) {
+            const float4 v = (v0 < voices) ? *reinterpret_cast<const float4*>(x + row * x_ld + v0) : make_float4(0, 0, 0, 0);
+            xin[0] = v.x; xin[1] = v.y; xin[2] = v.z; xin[3] = v.w;
+        } else if constexpr (MUL) {
+            xin[0] = (v0 < voices) ? x[row * x_ld + v0] : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const double w = t - p[i].off;
-            const double rel = (p[i].ir > 0.0) ? clip01(1.0 - w * p[i].ir) : 0.0;
-            const double env = (w < 0.0) ? held(p[i], t) : p[i].hold_off * rel;
+            const double env = level(p[i], t);
             y[i] = (OUT)(MUL ? env * (double)xin[i] : env);
         }
         OUT* dst = out + row * ld + v0;
@@ -118,11 +90,7 @@ extern "C" int sig_adsr(int64_t position, int32_t rate, int64_t rows, int32_t vo
 {
     SIG_CHECK_ARG(position >= 0 && rate > 0 && rows >= 0 && voices >= 0 && params && strides && out && out_ld >= voices);
     AdsrRows in;
-    for (int i = 0; i < 6; ++i) {
-        SIG_CHECK_ARG(params[i] != nullptr && (strides[i] == 0 || strides[i] == 1));
-        in.p[i] = params[i];
-        in.s[i] = strides[i];
-    }
+    SIG_CHECK_ARG(load_rows(params, strides, in));
     if (rows == 0 || voices == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (out_dtype == SIG_F32) return launch_adsr<float>(position, rate, rows, voices, in, static_cast<float*>(out), out_ld, nullptr, 0, s);
@@ -137,11 +105,7 @@ extern "C" int sig_adsr_apply(int64_t position, int32_t rate, int64_t rows, int3
     SIG_CHECK_ARG(position >= 0 && rate > 0 && rows >= 0 && voices >= 0 && params && strides && x && out);
     SIG_CHECK_ARG(out_ld >= voices && x_ld >= voices);
     AdsrRows in;
-    for (int i = 0; i < 6; ++i) {
-        SIG_CHECK_ARG(params[i] != nullptr && (strides[i] == 0 || strides[i] == 1));
-        in.p[i] = params[i];
-        in.s[i] = strides[i];
-    }
+    SIG_CHECK_ARG(load_rows(params, strides, in));
     if (rows == 0 || voices == 0) return 0;
     return launch_adsr<float>(position, rate, rows, voices, in, out, out_ld, x, x_ld, static_cast<hipStream_t>(stream));
 }

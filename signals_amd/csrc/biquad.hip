@@ -12,6 +12,7 @@
 // previous block's tail and is served by L2/Infinity Cache when the neighbouring wave ran recently.
 #include <cstdlib>
 
+#include "sig_adsr.h"
 #include "sig_biquad.h"
 
 namespace {
@@ -39,12 +40,15 @@ __device__ __forceinline__ void pack(double& v, const double (&y)[1]) { v = y[0]
 __device__ __forceinline__ void pack(float4& v, const double (&y)[4]) { v = make_float4((float)y[0], (float)y[1], (float)y[2], (float)y[3]); }
 __device__ __forceinline__ void pack(double4& v, const double (&y)[4]) { v = make_double4(y[0], y[1], y[2], y[3]); }
 
-template <typename T, int VPT, int kRing>   // kRing = rows of loads in flight per lane
+// ENV: multiply the stored rows by a per-voice ADSR envelope evaluated at the row's time (the
+// RingMod(Filter, ADSR) pair of BASELINE config 3 without a separate pass; sig_adsr.h).  n/rate is computed for
+// 64 rows at a time, one row per lane, and broadcast with v_readlane, like in the oscillator kernels.
+template <typename T, int VPT, int kRing, bool ENV>   // kRing = rows of loads in flight per lane
 __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
     int type, double rate, int64_t position, int N, int K, int ctx, int voices,
     const double* __restrict__ cutoff, int cs, int cutoff_blocks,
     const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld,
-    int voice_tiles, int* __restrict__ status)
+    int voice_tiles, int* __restrict__ status, sig_env::AdsrRows env)
 {
     using Vec = typename RowVec<T, VPT>::type;
     const int lane = threadIdx.x & 63;
@@ -70,6 +74,12 @@ __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
         z0[i] = 0.0; z1[i] = 0.0;
     }
     if (!ok && live && status) atomicOr(status, SIG_STATUS_BAD_CUTOFF);
+    sig_env::Voice ev[ENV ? VPT : 1];
+    double q_lane = 0.0;
+    if (ENV) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) ev[i] = sig_env::load_voice(env, (vc + i < voices) ? vc + i : vc);
+    }
 
     const int total = c + N;
     const T* src = in + (b * N - c) * in_ld + vc;        // first context row of this block
@@ -86,19 +96,29 @@ __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
 #pragma unroll
         for (int u = 0; u < kRing; ++u) {
             const int r = r0 + u;
-            if (r >= total) break;                                             // wave-uniform
+            const bool valid = r < total;                                      // wave-uniform; tail rows are no-ops
             double x[VPT], y[VPT];
             unpack(ring[u], x);
             const int rn = (r + kRing < total) ? r + kRing : total - 1;        // refill this slot
             ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * in_ld);
+            if (valid) {
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                // scipy _sosfilt, transposed direct form II, one rounding per op (contract off)
-                y[i] = q[i].b0 * x[i] + z0[i];
-                z0[i] = q[i].b1 * x[i] - q[i].a1 * y[i] + z1[i];
-                z1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
+                for (int i = 0; i < VPT; ++i) {
+                    // scipy _sosfilt, transposed direct form II, one rounding per op (contract off)
+                    y[i] = q[i].b0 * x[i] + z0[i];
+                    z0[i] = q[i].b1 * x[i] - q[i].a1 * y[i] + z1[i];
+                    z1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
+                }
             }
-            if (r >= c && live) {
+            if (ENV && valid) {
+                if ((r & 63) == 0) q_lane = (double)(p_b - c + r + lane) / rate;                       // wave-uniform
+                if (r >= c) {
+                    const double t = sig_readlane_f64(q_lane, r & 63);
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) y[i] *= sig_env::level(ev[i], t);
+                }
+            }
+            if (valid && r >= c && live) {
                 Vec o; pack(o, y);
                 *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
             }
@@ -115,12 +135,12 @@ __global__ __launch_bounds__(256) void biquad_coldstart_kernel(
 // output; at the block boundary the warm chain becomes the output chain.  Arithmetic per chain is
 // unchanged (same zero start, same rows, same order), so results are bit-identical to the plain kernel.
 // Needs N > ctx (at most two live chains) and one cutoff row for all blocks.
-template <typename T, int VPT, int kRing>
+template <typename T, int VPT, int kRing, bool ENV>
 __global__ __launch_bounds__(256) void biquad_walk_kernel(
     int type, double rate, int64_t position, int N, int K, int ctx, int voices, int span,
     const double* __restrict__ cutoff, int cs,
     const T* __restrict__ in, int64_t in_ld, T* __restrict__ out, int64_t out_ld,
-    int voice_tiles, int* __restrict__ status)
+    int voice_tiles, int* __restrict__ status, sig_env::AdsrRows env)
 {
     using Vec = typename RowVec<T, VPT>::type;
     const int lane = threadIdx.x & 63;
@@ -146,6 +166,12 @@ __global__ __launch_bounds__(256) void biquad_walk_kernel(
         a0[i] = a1[i] = w0[i] = w1[i] = 0.0;
     }
     if (!ok && live && status) atomicOr(status, SIG_STATUS_BAD_CUTOFF);
+    sig_env::Voice ev[ENV ? VPT : 1];
+    double q_lane = 0.0;
+    if (ENV) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) ev[i] = sig_env::load_voice(env, (vc + i < voices) ? vc + i : vc);
+    }
 
     const int total = c0 + nb * N;
     const T* src = in + (b0 * N - c0) * in_ld + vc;
@@ -186,6 +212,14 @@ __global__ __launch_bounds__(256) void biquad_walk_kernel(
                     w1[i] = q[i].b2 * x[i] - q[i].a2 * yw;
                 }
             }
+            if (ENV && valid) {
+                if ((r & 63) == 0) q_lane = (double)(p0 - c0 + r + lane) / rate;                       // wave-uniform
+                if (in_block >= 0) {
+                    const double t = sig_readlane_f64(q_lane, r & 63);
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) y[i] *= sig_env::level(ev[i], t);
+                }
+            }
             if (valid && in_block >= 0 && live) {
                 Vec o; pack(o, y);
                 *reinterpret_cast<Vec*>(dst + (int64_t)r * out_ld) = o;
@@ -207,10 +241,11 @@ static int biquad_variant() {
     return v;
 }
 
-template <typename T>
+template <typename T, bool ENV>
 int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K, int32_t ctx, int32_t voices,
                   const double* cutoff, int32_t cs, int32_t cutoff_blocks,
-                  const T* in, int64_t in_ld, T* out, int64_t out_ld, int32_t* status, hipStream_t stream)
+                  const T* in, int64_t in_ld, T* out, int64_t out_ld, int32_t* status, hipStream_t stream,
+                  const sig_env::AdsrRows& env)
 {
     auto ok = [&](int vpt) {
         return (voices % vpt == 0) && (in_ld % vpt == 0) && (out_ld % vpt == 0) &&
@@ -235,8 +270,8 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
             const int64_t items = (int64_t)tiles * ((K + span - 1) / span);
             const int64_t nwg = (items + 3) / 4;
             if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-#define SIG_WALK(V, R) biquad_walk_kernel<T, V, R><<<(unsigned)nwg, 256, 0, stream>>>( \
-                type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status)
+#define SIG_WALK(V, R) biquad_walk_kernel<T, V, R, ENV><<<(unsigned)nwg, 256, 0, stream>>>( \
+                type, (double)rate, position, N, K, ctx, voices, span, cutoff, cs, in, in_ld, out, out_ld, tiles, status, env)
             switch (wvpt * 100 + wring) {
                 case 116: SIG_WALK(1, 16); break;
                 case 132: SIG_WALK(1, 32); break;
@@ -266,8 +301,8 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
     const int64_t items = (int64_t)voice_tiles * K;
     const int64_t nwg = (items + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-#define SIG_BQ(V, R) biquad_coldstart_kernel<T, V, R><<<(unsigned)nwg, 256, 0, stream>>>( \
-        type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld, voice_tiles, status)
+#define SIG_BQ(V, R) biquad_coldstart_kernel<T, V, R, ENV><<<(unsigned)nwg, 256, 0, stream>>>( \
+        type, (double)rate, position, N, K, ctx, voices, cutoff, cs, cutoff_blocks, in, in_ld, out, out_ld, voice_tiles, status, env)
     switch (vpt * 100 + ring) {
         case 108: SIG_BQ(1, 8); break;
         case 116: SIG_BQ(1, 16); break;
@@ -286,12 +321,12 @@ int launch_biquad(int type, int32_t rate, int64_t position, int32_t N, int32_t K
 
 }  // namespace
 
-extern "C" int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
-                                    int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
-                                    const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
-                                    const void* in, int64_t in_ld, int64_t in_history,
-                                    void* out, int64_t out_ld, int32_t dtype,
-                                    int32_t* status, void* stream)
+namespace {
+
+int run_biquad(int type, int32_t rate, int64_t position, int32_t block_frames, int32_t nblocks, int32_t context,
+               int32_t voices, const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+               const void* in, int64_t in_ld, int64_t in_history, void* out, int64_t out_ld, int32_t dtype,
+               int32_t* status, void* stream, const sig_env::AdsrRows* env)
 {
     SIG_CHECK_ARG(type == SIG_FILT_LOWPASS || type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
@@ -307,13 +342,44 @@ extern "C" int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
     }
     if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (dtype == SIG_F32)
-        return launch_biquad<float>(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride,
-                                    cutoff_blocks, static_cast<const float*>(in), in_ld, static_cast<float*>(out), out_ld,
-                                    status, s);
-    if (dtype == SIG_F64)
-        return launch_biquad<double>(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride,
-                                     cutoff_blocks, static_cast<const double*>(in), in_ld, static_cast<double*>(out), out_ld,
-                                     status, s);
+    const sig_env::AdsrRows none{};
+    if (dtype == SIG_F32) {
+        const float* x = static_cast<const float*>(in);
+        float* y = static_cast<float*>(out);
+        return env ? launch_biquad<float, true>(type, rate, position, block_frames, nblocks, context, voices, cutoff,
+                                                cutoff_stride, cutoff_blocks, x, in_ld, y, out_ld, status, s, *env)
+                   : launch_biquad<float, false>(type, rate, position, block_frames, nblocks, context, voices, cutoff,
+                                                 cutoff_stride, cutoff_blocks, x, in_ld, y, out_ld, status, s, none);
+    }
+    if (dtype == SIG_F64 && !env)
+        return launch_biquad<double, false>(type, rate, position, block_frames, nblocks, context, voices, cutoff,
+                                            cutoff_stride, cutoff_blocks, static_cast<const double*>(in), in_ld,
+                                            static_cast<double*>(out), out_ld, status, s, none);
     return (int)hipErrorInvalidValue;
+}
+
+}  // namespace
+
+extern "C" int sig_biquad_coldstart(int type, int32_t rate, int64_t position,
+                                    int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                    const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                                    const void* in, int64_t in_ld, int64_t in_history,
+                                    void* out, int64_t out_ld, int32_t dtype,
+                                    int32_t* status, void* stream)
+{
+    return run_biquad(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride, cutoff_blocks,
+                      in, in_ld, in_history, out, out_ld, dtype, status, stream, nullptr);
+}
+
+extern "C" int sig_biquad_coldstart_env(int type, int32_t rate, int64_t position,
+                                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                        const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                                        const double* const* adsr_params, const int32_t* adsr_strides,
+                                        const float* in, int64_t in_ld, int64_t in_history,
+                                        float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    sig_env::AdsrRows env;
+    SIG_CHECK_ARG(sig_env::load_rows(adsr_params, adsr_strides, env));
+    return run_biquad(type, rate, position, block_frames, nblocks, context, voices, cutoff, cutoff_stride, cutoff_blocks,
+                      in, in_ld, in_history, out, out_ld, SIG_F32, status, stream, &env);
 }

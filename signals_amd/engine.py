@@ -461,14 +461,20 @@ class _Batch:
         return result
 
     def _ringmod_with_envelope(self, node, channels, hist, rows):
-        """RingMod(x, ADSR) with an envelope nobody else reads: envelope * x in one pass (sig_adsr_apply)"""
+        """RingMod(x, ADSR) with an envelope nobody else reads: the envelope multiplies x on the fly -- in the
+        epilogue of the filter that produces x when nothing else reads that filter (sig_biquad_coldstart_env),
+        else in one envelope * x pass (sig_adsr_apply)"""
         for env_port, x_port in ((node.right, node.left), (node.left, node.right)):
             env = env_port.sig
             if (isinstance(env, ext.ADSR) and env.get_state().enabled and len(env.outputs_with_ports) == 1
                     and not _modulated(env) and x_port.sig is not None and not isinstance(x_port.sig, ext.ADSR)):
-                x = self._operand(x_port, channels, hist)
                 ctl = env.control_rows(lambda bound: self._control_const(bound, bound.name))
                 voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))[1]
+                flt = x_port.sig
+                if (isinstance(flt, fx.SingleCritFilter) and flt.get_state().enabled and len(flt.outputs_with_ports) == 1
+                        and voices in (1, channels) and (flt, channels) not in self._memo):
+                    return self._filter(flt, channels, hist, rows, envelope=ctl, owner_node=node)
+                x = self._operand(x_port, channels, hist)
                 if x.shape[0] == 1 or x.shape[1] != voices or x.dtype != AUDIO_DTYPE:
                     return None
                 result = torch.empty((rows, voices), dtype=AUDIO_DTYPE, device=runtime.device())
@@ -553,7 +559,10 @@ class _Batch:
     )
 
     # -------------------------------------------------------------- filters
-    def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int) -> torch.Tensor:
+    def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int, envelope: dict | None = None,
+                owner_node: Emitter | None = None) -> torch.Tensor:
+        """`envelope` / `owner_node`: the filter runs on behalf of RingMod(filter, ADSR) -- its stored rows are
+        multiplied by the envelope and the buffer (history rows, tail) belongs to that RingMod node"""
         o = self.owner
         N, K, pos = self.N, self.K, self.pos
         band = isinstance(node, fx.DoubleCritFilter)
@@ -591,11 +600,11 @@ class _Batch:
                                                      status=status),
                       units=N * K * channels)
         else:
-            o._launch(f'biquad_coldstart[{btype}]',
+            o._launch(f'biquad_coldstart[{btype}{",env" if envelope else ""}]',
                       lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
-                                                       status=status),
+                                                       status=status, envelope=envelope),
                       units=N * K * channels)
-        self._own_history(node, channels, hist, result)
+        self._own_history(owner_node or node, channels, hist, result)
         return result
 
     def _own_history(self, node: Emitter, channels: int, hist: int, result: torch.Tensor) -> None:

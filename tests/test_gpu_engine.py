@@ -565,18 +565,41 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
 
 
 def test_ringmod_with_adsr_in_one_pass():
-    """RingMod(x, ADSR) -> sig_adsr_apply when the envelope has no other consumer; C3 stays within 1e-6 of the oracle"""
+    """RingMod(Filter, ADSR) -> envelope in the filter's epilogue (sig_biquad_coldstart_env) when neither the
+    envelope nor the filter has another consumer; RingMod(x, ADSR) -> sig_adsr_apply otherwise; C3 stays within
+    1e-6 of the oracle either way"""
     from oracle import chain_ref as R
+    from signals_amd.chain import ext
     from signals_amd.engine import BatchRenderer, KernelTimer
     V, N, K = 16, 1024, 3
+    o = lambda p: R.Osc('Sawtooth', R.Fixed(p['hertz']), R.Fixed(p['phase']))
+
     bus, p = c3_graph(V)
     timer = KernelTimer()
-    got = BatchRenderer(bus, 1, RATE, timer=timer).render(0, N, K).cpu().numpy()
+    r = BatchRenderer(bus, 1, RATE, timer=timer)
+    got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
     torch.cuda.synchronize()
     names = set(timer.summary())
-    assert 'adsr_apply' in names and 'adsr' not in names and not any(n.startswith('elementwise[RingMod') for n in names), names
-    o = R.Osc('Sawtooth', R.Fixed(p['hertz']), R.Fixed(p['phase']))
-    f2 = R.Filter('lp', R.Filter('lp', o, R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
-    ref = R.sum_bus(R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, K, V))
+    assert 'biquad_coldstart[lp,env]' in names and 'adsr_apply' not in names and 'adsr' not in names, names
+    assert not any(n.startswith('elementwise[RingMod') for n in names), names
+    f2 = R.Filter('lp', R.Filter('lp', o(p), R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
+    ref = R.sum_bus(R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, 2 * K, V))
     assert maxerr(got, f32(ref)) < 1e-6
-    assert maxerr(got, batched(c3_graph(V)[0], 0, N, K, 1)) < 1e-6
+    assert maxerr(got, batched(c3_graph(V)[0], 0, N, 2 * K, 1)) < 1e-6
+
+    # the filter has a second consumer: its rows must exist un-enveloped, the envelope is applied in one pass
+    bus, p = c3_graph(V)
+    rm = bus.input.sig
+    both = fx_mix(rm, rm.left.sig)
+    timer = KernelTimer()
+    got = BatchRenderer(both, V, RATE, timer=timer).render(0, N, K).cpu().numpy()
+    torch.cuda.synchronize()
+    names = set(timer.summary())
+    assert 'adsr_apply' in names and 'biquad_coldstart[lp,env]' not in names, names
+    assert np.array_equal(got, stream(fx_mix(*(lambda b: (b.input.sig, b.input.sig.left.sig))(c3_graph(V)[0])), 0, N, K, V))
+
+
+def fx_mix(a, b):
+    from signals_amd.chain import fx
+    m = fx.RingMod(); m.left = a; m.right = b
+    return m
