@@ -1,18 +1,32 @@
-// Fused voice chain for gfx950: Osc -> cold-start Butterworth biquad -> [x per-voice gain] -> f32 store,
-// K blocks per launch.  Chosen by the batched engine when a LowPass/HighPass reads an oscillator nobody
-// else consumes (and, optionally, feeds a Gain nobody else consumes): the oscillator samples never touch
-// HBM, so the stage costs 4 B/voice-sample (the store) instead of 4 + 8 (+ 8).
+// Fused voice chain for gfx950: Osc -> cold-start Butterworth biquad -> [x per-voice gain] -> f32 store or
+// -> [pan x gain] -> bus partial sums, K blocks per launch.  Chosen by the batched engine when a LowPass/HighPass
+// reads an oscillator nobody else consumes (and, optionally, feeds a Gain and a SumBus nobody else consumes): the
+// oscillator samples never touch HBM, so the stage costs 4 B/voice-sample (the store) or ~0.13 B (the bus
+// partials) instead of 4 + 8 (+ 8 + 4).
 //
 // Same design and phase arithmetic as the node kernels (sig_osc.h, sig_biquad.h; reference osc.py:26-62,
-// fx.py:85-121, fx.py:51-52): f64 phase, f64 recurrence from zero state over [c context rows | block], context
-// rows are recomputed (the oscillator is position-pure), the filter input is the oscillator's f64 sample
-// rather than its f32-rounded store, the recurrence uses fused multiply-adds (one rounding per FMA instead of
-// sosfilt's two), and the gain multiplies the f64 filter output before the single f32 rounding -- i.e.
-// closer to the exact f64 recurrence than the materialised path, and 1e-6-parity with the reference.
+// fx.py:85-121, fx.py:51-52): f64 phase, f64 recurrence from zero state over [c context rows | block].  What
+// differs from the per-node path, all of it below 1e-9 of the f64 reference and far inside the 1e-6 bar:
+//   * the filter input is the oscillator's f64 sample, not its f32-rounded store;
+//   * the recurrence runs on the b0-normalised filter  y' = y / b0  (b = [1, +-2, 1] for a Butterworth
+//     low/high-pass), 4 fused multiply-adds per row instead of sosfilt's 8 separately rounded operations; b0 is
+//     folded into the per-voice output weight (gain, pan), which is applied in f64 before the one f32 rounding;
+//   * SPAN WALKER: a lane owns `span` consecutive blocks of its voices.  Block b+1 cold-starts from zero state
+//     at its row -c, i.e. inside block b: its warm-up runs as a second recurrence on the oscillator sample the
+//     lane has just computed for block b, and becomes the output recurrence at the block boundary.  Every
+//     oscillator sample is computed once (not (N+c)/N times); the arithmetic of each chain is unchanged;
+//   * Sine, while every |t| of the span is < 2^24 cycles and the voice advances by at most a quarter turn per
+//     row (|hertz| <= rate/4 after aliasing): the oscillator is the two-term recurrence in difference (Reinsch)
+//     form   x <- x + d;  d <- d - m x,   m = 4 sin^2(theta/2),  d_0 = 2 sin(theta/2) cos(phi_0 + theta/2),
+//     seeded once per span from the reference's own t at the span's first row (sin by the f64 polynomial).
+//     2 f64 ops per sample, no divide, no conversion, no v_sin_f32; rounding grows like rows x 1e-16 (the
+//     difference form has no 1/theta amplification), i.e. ~1e-13 from sin(2 pi t) instead of v_sin_f32's 1e-7.
+//     Otherwise (wave-uniform test) the exact per-row phase of sig_osc.h is used, as for the other waveforms.
 //
-// Mapping: one wave = 64*VPT consecutive voices of ONE block, lanes walk c+N rows serially; the per-row
-// quotient n/rate (IEEE f64 divide) is computed 64 rows at a time, one row per lane, and broadcast with
-// v_readlane.  f64-VALU-bound: ~(15 osc + 9 filter + 2) x (N+c)/N f64-rate ops per voice-sample.
+// Mapping: one wave = 64*VPT consecutive voices x `span` consecutive blocks, lanes walk rows serially.  On the
+// exact-phase path the per-row quotient n/rate (IEEE f64 divide) is computed 64 rows at a time, one row per
+// lane, and broadcast with v_readlane.  f64-VALU-bound: Sine ~ 2 (osc) + 4 (N+c')/N (filter) + C (bus) f64
+// ops per voice-sample.
 #include <cstdlib>
 #include <type_traits>
 
@@ -33,10 +47,22 @@ __device__ __forceinline__ void put(float& v, const float (&y)[1]) { v = y[0]; }
 __device__ __forceinline__ void put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
 __device__ __forceinline__ void put(float4& v, const float (&y)[4]) { v = make_float4(y[0], y[1], y[2], y[3]); }
 
-#ifndef SIG_FUSED_ILP
-#define SIG_FUSED_ILP 4
+// Register budget per voices-per-lane variant, as waves per SIMD the compiler must leave room for (0 = its own
+// choice): the row groups below are straight-line code with many independent chains, which the scheduler would
+// otherwise spread over every register it can get.  Values from tools/sweep_fused.sh.
+#ifndef SIG_FUSED_OCC1
+#define SIG_FUSED_OCC1 0
 #endif
-constexpr int kIlp = SIG_FUSED_ILP;     // rows whose oscillator samples are computed ahead of the recurrence
+#ifndef SIG_FUSED_OCC2
+#define SIG_FUSED_OCC2 0
+#endif
+#ifndef SIG_FUSED_OCC4
+#define SIG_FUSED_OCC4 0
+#endif
+template <int VPT> struct Occ;
+template <> struct Occ<1> { static constexpr int lo = SIG_FUSED_OCC1 ? SIG_FUSED_OCC1 : 1, hi = SIG_FUSED_OCC1 ? SIG_FUSED_OCC1 : 8; };
+template <> struct Occ<2> { static constexpr int lo = SIG_FUSED_OCC2 ? SIG_FUSED_OCC2 : 1, hi = SIG_FUSED_OCC2 ? SIG_FUSED_OCC2 : 8; };
+template <> struct Occ<4> { static constexpr int lo = SIG_FUSED_OCC4 ? SIG_FUSED_OCC4 : 1, hi = SIG_FUSED_OCC4 ? SIG_FUSED_OCC4 : 8; };
 
 struct FusedArgs {
     int type; double rate; int64_t position; int N, K, ctx, voices;
@@ -44,256 +70,285 @@ struct FusedArgs {
     const double* cutoff; int cs; const double* gain; int gs;
     float* out; int64_t out_ld; int voice_tiles; int* status;
     const int64_t* pos_dev = nullptr;        // when set, the position is read from device memory (hipGraph replay)
+    int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
 };
 
-template <int KIND, int VPT, bool GAIN>
-__global__ __launch_bounds__(256) void fused_osc_biquad_kernel(FusedArgs a)
-{
-    using Vec = typename OutVec<VPT>::type;
-    const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int vt = (int)(item % a.voice_tiles);
-    const int64_t b = item / a.voice_tiles;
-    if (b >= a.K) return;                                                     // wave-uniform
-    const int v0 = (vt * SIG_WAVE + lane) * VPT;
-    const bool live = v0 < a.voices;
-    const int vc = live ? v0 : 0;
-
-    const int64_t p_b = (a.pos_dev ? *a.pos_dev : a.position) + b * a.N;
-    const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
-    const int64_t n0 = p_b - c;                                               // absolute frame of row 0
-    const int total = c + a.N;
-
-    Biquad q[VPT];
-    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], g[VPT], dr[VPT];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int v = (vc + i < a.voices) ? vc + i : vc;
-        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q[i]);
-        hz[i] = a.hertz[(int64_t)v * a.hs];
-        ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
-        g[i] = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
-        z0[i] = 0.0; z1[i] = 0.0;
-        const double d = hz[i] / a.rate;                                       // revolutions per row
-        dr[i] = d - rint(d);
-    }
-    if (!ok && live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
-
-    float* dst = a.out + (b * a.N - c) * a.out_ld + vc;                      // rows < c are never stored
-
-    // rows [r_begin, r_end): STORE=false warms the filter up (context rows), STORE=true keeps the block
-    auto walk = [&](int r_begin, int r_end, auto store_tag) {
-        constexpr bool STORE = decltype(store_tag)::value;
-        for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
-            const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
-            const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
-            // Sine: advance the phase by hertz/rate per row inside the chunk when every |t| of the wave is small
-            bool fast = false;
-            double f0[VPT];
-            if (KIND == SIG_OSC_SINE) {
-                bool small = true;
-#pragma unroll
-                for (int i = 0; i < VPT; ++i) {
-                    const double t_first = sig_readlane_f64(q_lane, 0) * hz[i] + ph[i];
-                    const double t_last = sig_readlane_f64(q_lane, lim - 1) * hz[i] + ph[i];
-                    small &= fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT;
-                    f0[i] = t_first - rint(t_first);                           // exact
-                }
-                fast = __all(small);
-            }
-            // oscillator samples of kIlp rows are independent of the filter state: compute them first so their
-            // long dependent chains overlap, then run the (serial) recurrence over them
-            auto rows = [&](int j, auto count_tag) {
-                constexpr int CNT = decltype(count_tag)::value;
-                double xs[CNT][VPT];
-                if (KIND == SIG_OSC_SINE && fast) {
-#pragma unroll
-                    for (int u = 0; u < CNT; ++u) {
-                        const double jj = (double)(j + u);
-#pragma unroll
-                        for (int i = 0; i < VPT; ++i) xs[u][i] = (double)sig_osc::osc_sine_f32_fast(f0[i], dr[i], jj);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < CNT; ++u) {
-                        const double t_s = sig_readlane_f64(q_lane, j + u);
-#pragma unroll
-                        for (int i = 0; i < VPT; ++i) {
-                            const double t = t_s * hz[i] + ph[i];
-                            xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                               : sig_osc::osc_wave<KIND, double>(t);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < CNT; ++u) {
-                    float y32[VPT];
-#pragma unroll
-                    for (int i = 0; i < VPT; ++i) {
-                        const double x = xs[u][i];
-                        // DF2T with fused multiply-adds: 5 f64 ops instead of sosfilt's 8 separately rounded ones (this
-                        // kernel is f64-issue-bound; the per-node biquad kernels keep scipy's exact operation order)
-                        const double y = fma(q[i].b0, x, z0[i]);
-                        z0[i] = fma(q[i].b1, x, fma(-q[i].a1, y, z1[i]));
-                        z1[i] = fma(q[i].b2, x, -q[i].a2 * y);
-                        if (STORE) y32[i] = (float)(GAIN ? y * g[i] : y);
-                    }
-                    if (STORE && live) {
-                        Vec o; put(o, y32);
-                        *reinterpret_cast<Vec*>(dst + (int64_t)(r0 + j + u) * a.out_ld) = o;
-                    }
-                }
-            };
-            int j = 0;
-            for (; j + kIlp <= lim; j += kIlp) rows(j, std::integral_constant<int, kIlp>{});
-            for (; j < lim; ++j) rows(j, std::integral_constant<int, 1>{});
-        }
-    };
-    walk(0, c, std::false_type{});
-    walk(c, total, std::true_type{});
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Fused voice chain + bus: the same chain, but instead of storing each voice the wave reduces its
-// 64*VPT voices into the C bus channels:  partial[tile][row][c] = sum_v pan[c][v] * (gain[v] * y[v]).
-// Lanes are voices, so a row's sum is a cross-lane sum; doing it per row with a butterfly would cost as
-// much as the chain itself, so rows are staged kGroup at a time in a wave-private LDS tile
-// [pair = row*C + c][lane] (row stride 65 doubles: conflict-free for the transposed read) and reduced by
-// lane = pair: 16 LDS reads + 2 shuffles per lane per kGroup rows.  A second tiny kernel adds the voice
-// tiles in a fixed order (deterministic, no atomics) and rounds to f32.  Nothing but parameters is read
-// from HBM and nothing but the bus is written: 8*C B per frame instead of 4 B per voice-sample.
+// Bus: partial[tile][row][c] = sum over the wave's 64*VPT voices of pan[c][v] * gain[v] * y[v].  Lanes are
+// voices, so a row's sum is a cross-lane sum; doing it per row with a butterfly would cost as much as the chain
+// itself, so rows are staged kPairs/C at a time in a wave-private LDS tile [pair = row*C + c][lane] (row stride
+// 65 doubles: conflict-free for the transposed read) and reduced by lane = pair: 16 LDS reads + 2 shuffles per
+// lane per flush.  A second tiny kernel adds the voice tiles in a fixed order (deterministic, no atomics) and
+// rounds to f32.  Nothing but parameters is read from HBM and nothing but the bus is written.
 constexpr int kPairs = 16;                 // (row, channel) pairs reduced per flush
 constexpr int kTileStride = 65;            // doubles
 
 struct BusArgs { const double* pan; int64_t pan_ld; double* partials; int64_t rows; };
 
+// sin(2 pi f) and cos(2 pi f) in f64 (~1 ulp), any |f| < 2^50: quarter-range reduction by the magic-number
+// rint of sig_osc.h, true 2 pi as hi + lo
+__device__ __forceinline__ double sin2pi(double f) {
+    const double u = fma(f, 2.0, sig_osc::kRoundMagic);
+    const double k = u - sig_osc::kRoundMagic;
+    const double rq = fma(k, -0.5, f);
+    const double y = sig_osc::sin_poly(fma(rq, sig_osc::kTwoPiHi, rq * sig_osc::kTwoPiLo));
+    return __hiloint2double(__double2hiint(y) ^ (int)(((unsigned)__double2loint(u) & 1u) << 31), __double2loint(y));
+}
+
+// C == 0: store (float)(weight * y) to a.out; C > 0: C bus channels into bus.partials
 template <int KIND, int VPT, bool GAIN, int C>
-__global__ __launch_bounds__(256) void fused_voice_bus_kernel(FusedArgs a, BusArgs bus)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
+void fused_walk_kernel(FusedArgs a, BusArgs bus)
 {
-    constexpr int R = kPairs / C;          // rows per flush
-    __shared__ double lds[4][kPairs * kTileStride];
+    constexpr bool BUS = C > 0;
+    constexpr int CC = BUS ? C : 1;
+    constexpr int R = kPairs / CC;         // rows per flush
+    using Vec = typename OutVec<VPT>::type;
+    __shared__ double lds[BUS ? 4 : 1][BUS ? kPairs * kTileStride : 1];
     const int lane = threadIdx.x & 63;
-    double* tile = lds[threadIdx.x >> 6];
+    double* tile = lds[BUS ? (threadIdx.x >> 6) : 0];
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int vt = (int)(item % a.voice_tiles);
-    const int64_t b = item / a.voice_tiles;
-    if (b >= a.K) return;                                                     // wave-uniform
+    const int64_t b_first = (item / a.voice_tiles) * a.span;
+    if (b_first >= a.K) return;                                               // wave-uniform
+    const int nb = (int)((a.K - b_first < (int64_t)a.span) ? a.K - b_first : (int64_t)a.span);
     const int v0 = (vt * SIG_WAVE + lane) * VPT;
+    const bool live0 = v0 < a.voices;
+    const int vc = live0 ? v0 : 0;
 
-    const int64_t p_b = (a.pos_dev ? *a.pos_dev : a.position) + b * a.N;
-    const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
-    const int64_t n0 = p_b - c;
-    const int total = c + a.N;
+    const int64_t p0 = (a.pos_dev ? *a.pos_dev : a.position) + b_first * a.N;  // first frame of the span's first block
+    const int c0 = (int)((p0 < (int64_t)a.ctx) ? p0 : (int64_t)a.ctx);
+    const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
 
-    Biquad q[VPT];
-    double z0[VPT], z1[VPT], hz[VPT], ph[VPT], dr[VPT], w[C][VPT];
+    double na1[VPT], na2[VPT], z0[VPT], z1[VPT], wt[CC][VPT];
     bool ok = true, any_live = false;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const bool live = v0 + i < a.voices;
-        const int v = live ? v0 + i : 0;                                       // dead lanes shadow voice 0 ...
+        const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
         any_live |= live;
-        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q[i]) || !live;
-        hz[i] = a.hertz[(int64_t)v * a.hs];
-        ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
-        const double gn = GAIN ? a.gain[(int64_t)v * a.gs] : 1.0;
+        Biquad q;
+        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q) || !live;
+        na1[i] = -q.a1; na2[i] = -q.a2;
+        const double scale = GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0
-            w[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * gn : gn) : 0.0;   // pan * gain, once per voice
-        z0[i] = 0.0; z1[i] = 0.0;
-        const double d = hz[i] / a.rate;                                       // revolutions per row
-        dr[i] = d - rint(d);
+        for (int ch = 0; ch < CC; ++ch)                                        // ... with weight exactly 0 on the bus
+            wt[ch][i] = BUS ? (live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0) : scale;
+        z0[i] = z1[i] = 0.0;
     }
     if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
-    double* dst = bus.partials + ((int64_t)vt * bus.rows + b * a.N) * C;      // [tile][row][c], row 0 = block start
-    const int pair = lane & (kPairs - 1), quarter = lane >> 4;
+    // hertz / phase of the lane's voices (re-read where needed rather than kept live across the row loops)
+    auto load_hz_ph = [&](double (&hz)[VPT], double (&ph)[VPT]) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = (v0 + i < a.voices) ? v0 + i : vc;
+            hz[i] = a.hertz[(int64_t)v * a.hs];
+            ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+        }
+    };
 
-    auto flush = [&](int row_first, int nrows) {                               // rows [row_first, row_first+nrows) of the block
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // Sine as a two-term recurrence (see the header): seeded at the span's first row
+    bool fast = false;
+    double sx[VPT], sdl[VPT], snm[VPT];                                        // x, d, -m
+    if (KIND == SIG_OSC_SINE) {
+        double hz[VPT], ph[VPT];
+        load_hz_ph(hz, ph);
+        const double q_first = (double)(p0 - c0) / a.rate;                     // osc.py:32
+        const double q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
+        bool small = true;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const double t_first = q_first * hz[i] + ph[i];
+            const double t_last = q_last * hz[i] + ph[i];                      // t is monotonic in the row
+            const double d = hz[i] / a.rate;                                   // revolutions per row
+            const double dr = d - rint(d);
+            small &= fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT && fabs(dr) <= 0.25;
+            const double f0 = t_first - rint(t_first);                         // exact, |f0| <= 0.5
+            const double sh = sin2pi(0.5 * dr);                                // sin(theta / 2)
+            sx[i] = sin2pi(f0);
+            sdl[i] = 2.0 * sh * sin2pi(f0 + 0.5 * dr + 0.25);                  // x_1 - x_0
+            snm[i] = -4.0 * sh * sh;
+        }
+        fast = __all(small);
+    }
+
+    float* dst = BUS ? nullptr : a.out + vc;                                   // row index = frame - position
+    double* dstp = BUS ? bus.partials + (int64_t)vt * bus.rows * C : nullptr;  // [tile][row][c]
+    const double* col = tile + (lane & (kPairs - 1)) * kTileStride + (lane >> 4) * 16;   // this lane's 16 values of a flush
+    int staged = 0;                                                            // rows in the tile
+    double* slot = tile + lane;                                                // where the next row's sums go
+    int64_t first = b_first * a.N;                                             // output row of the first staged row
+    int64_t n_cur = p0 - c0;                                                   // absolute frame of the next row
+
+    // flush = transposed read of the tile (16 values per lane) + sum + 2 shuffles + store.  The wave's LDS
+    // operations execute in order, so the reads may be issued right after the last write of a group and consumed
+    // a whole group of rows later (flush_issue / flush_finish), which hides their latency.
+    auto flush_issue = [&](double (&pv)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[k] = col[k];
+    };
+    auto flush_finish = [&](const double (&pv)[16], int64_t row0, int nrows) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += tile[pair * kTileStride + quarter * 16 + k];
+        for (int k = 0; k < 16; ++k) s += pv[k];
         s += sig_shfl_xor_f64(s, 16);
         s += sig_shfl_xor_f64(s, 32);
-        if (lane < nrows * C) dst[(int64_t)row_first * C + lane] = s;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nrows * CC) dstp[row0 * CC + lane] = s;
+    };
+    auto flush_now = [&]() {
+        double pv[16];
+        flush_issue(pv);
+        flush_finish(pv, first, staged);
+        first += staged;
+        staged = 0;
+        slot = tile + lane;
     };
 
-    auto walk = [&](int r_begin, int r_end, auto store_tag) {
-        constexpr bool STORE = decltype(store_tag)::value;
-        int staged = 0, first = r_begin - c;
-        for (int r0 = r_begin; r0 < r_end; r0 += SIG_WAVE) {
-            const double q_lane = (double)(n0 + r0 + lane) / a.rate;         // osc.py:32, one row per lane
-            const int lim = (r_end - r0 < SIG_WAVE) ? r_end - r0 : SIG_WAVE;
-            // Sine: advance the phase by hertz/rate per row inside the chunk when every |t| of the wave is small
-            bool fast = false;
-            double f0[VPT];
-            if (KIND == SIG_OSC_SINE) {
-                bool small = true;
+    // one row of the lane's recurrences: y = output of the current block's chain; WARM rows also advance the
+    // next block's warm-up chain on the same input
+    auto chains = [&](const double (&x)[VPT], double (&y)[VPT], double (&w0)[VPT], double (&w1)[VPT], auto warm_tag) {
+        constexpr bool WARM = decltype(warm_tag)::value;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            y[i] = x[i] + z0[i];                                               // DF2T of [1, s2, 1] / [1, a1, a2]
+            z0[i] = fma(na1[i], y[i], fma(s2, x[i], z1[i]));
+            z1[i] = fma(na2[i], y[i], x[i]);
+            if (WARM) {
+                const double yw = x[i] + w0[i];
+                w0[i] = fma(na1[i], yw, fma(s2, x[i], w1[i]));
+                w1[i] = fma(na2[i], yw, x[i]);
+            }
+        }
+    };
+    auto to_tile = [&](const double (&y)[VPT], double* where) {
+#pragma unroll
+        for (int ch = 0; ch < CC; ++ch) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) acc = fma(wt[ch][i], y[i], acc);
+            where[ch * kTileStride] = acc;
+        }
+    };
+    auto to_out = [&](const double (&y)[VPT], int64_t out_row) {
+        float y32[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) y32[i] = (float)(y[i] * wt[0][i]);
+        if (live0) {
+            Vec o; put(o, y32);
+            *reinterpret_cast<Vec*>(dst + out_row * a.out_ld) = o;
+        }
+    };
+
+    // `count` consecutive rows from n_cur on; OUT rows go to output rows out_row, out_row + 1, ...
+    auto walk = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, auto fast_tag) {
+        constexpr bool OUT = decltype(out_tag)::value, FAST = decltype(fast_tag)::value;
+        double hz[VPT], ph[VPT], q_lane = 0.0;
+        int64_t qbase = 0;
+        bool q_valid = false;
+        if (!FAST) load_hz_ph(hz, ph);
+        // exact phase: n/rate (IEEE divide) for 64 rows at a time, one row per lane (osc.py:32)
+        auto ensure = [&](int rows) {
+            if (!FAST && (!q_valid || n_cur + rows > qbase + SIG_WAVE)) {     // wave-uniform
+                qbase = n_cur;
+                q_lane = (double)(qbase + lane) / a.rate;
+                q_valid = true;
+            }
+        };
+        auto gen = [&](double (&x)[VPT], int k) {                              // sample of row n_cur + k
+            if (FAST) {
 #pragma unroll
                 for (int i = 0; i < VPT; ++i) {
-                    const double t_first = sig_readlane_f64(q_lane, 0) * hz[i] + ph[i];
-                    const double t_last = sig_readlane_f64(q_lane, lim - 1) * hz[i] + ph[i];
-                    small &= fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT;
-                    f0[i] = t_first - rint(t_first);                           // exact
+                    x[i] = sx[i];
+                    sx[i] = x[i] + sdl[i];
+                    sdl[i] = fma(snm[i], sx[i], sdl[i]);
                 }
-                fast = __all(small);
+            } else {
+                const double t_s = sig_readlane_f64(q_lane, (int)(n_cur - qbase) + k);
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const double t = t_s * hz[i] + ph[i];
+                    x[i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+                }
             }
-            auto rows = [&](int j, auto count_tag) {
-                constexpr int CNT = decltype(count_tag)::value;
-                double xs[CNT][VPT];
-                if (KIND == SIG_OSC_SINE && fast) {
+        };
+        int done = 0;
+        // the exact-phase Sine path is the rare one (positions beyond 2^24 cycles): rolled loops, so that its
+        // register needs do not set the kernel's budget
+        constexpr bool GROUPED = FAST || KIND != SIG_OSC_SINE;
+        if (!OUT || !BUS) {
+            constexpr int U = GROUPED ? 4 : 1;                                 // rows per unrolled step
+            for (; done + U <= count; done += U) {
+                ensure(U);
 #pragma unroll
-                    for (int u = 0; u < CNT; ++u) {
-                        const double jj = (double)(j + u);
-#pragma unroll
-                        for (int i = 0; i < VPT; ++i) xs[u][i] = (double)sig_osc::osc_sine_f32_fast(f0[i], dr[i], jj);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < CNT; ++u) {
-                        const double t_s = sig_readlane_f64(q_lane, j + u);
-#pragma unroll
-                        for (int i = 0; i < VPT; ++i) {
-                            const double t = t_s * hz[i] + ph[i];
-                            xs[u][i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t)
-                                                               : sig_osc::osc_wave<KIND, double>(t);
-                        }
-                    }
+                for (int k = 0; k < U; ++k) {
+                    double x[VPT], y[VPT];
+                    gen(x, k);
+                    chains(x, y, w0, w1, warm_tag);
+                    if (OUT) to_out(y, out_row + done + k);
                 }
-#pragma unroll
-                for (int u = 0; u < CNT; ++u) {
-                    double acc[C];
-#pragma unroll
-                    for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0;
-#pragma unroll
-                    for (int i = 0; i < VPT; ++i) {
-                        const double x = xs[u][i];
-                        const double y = fma(q[i].b0, x, z0[i]);              // fused DF2T, see fused_osc_biquad_kernel
-                        z0[i] = fma(q[i].b1, x, fma(-q[i].a1, y, z1[i]));
-                        z1[i] = fma(q[i].b2, x, -q[i].a2 * y);
-                        if (STORE) {
-#pragma unroll
-                            for (int ch = 0; ch < C; ++ch) acc[ch] = fma(w[ch][i], y, acc[ch]);
-                        }
-                    }
-                    if (STORE) {
-#pragma unroll
-                        for (int ch = 0; ch < C; ++ch) tile[(staged * C + ch) * kTileStride + lane] = acc[ch];
-                        if (++staged == R) { flush(first, R); first += R; staged = 0; }
-                    }
-                }
-            };
-            int j = 0;
-            for (; j + kIlp <= lim; j += kIlp) rows(j, std::integral_constant<int, kIlp>{});
-            for (; j < lim; ++j) rows(j, std::integral_constant<int, 1>{});
+                n_cur += U;
+            }
+            for (; done < count; ++done) {
+                double x[VPT], y[VPT];
+                ensure(1);
+                gen(x, 0);
+                chains(x, y, w0, w1, warm_tag);
+                if (OUT) to_out(y, out_row + done);
+                ++n_cur;
+            }
+            return;
         }
-        if (STORE && staged) flush(first, staged);
+        auto single = [&]() {
+            double x[VPT], y[VPT];
+            ensure(1);
+            gen(x, 0);
+            chains(x, y, w0, w1, warm_tag);
+            to_tile(y, slot);
+            slot += CC * kTileStride;
+            ++n_cur; ++done;
+            if (++staged == R) flush_now();
+        };
+        while (staged != 0 && done < count) single();                          // until the tile is empty
+        double pend[16];
+        int64_t pend_row = 0;
+        bool have = false;
+        for (; GROUPED && done + R <= count; done += R) {                      // whole tiles, flush one group behind
+            ensure(R);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double x[VPT], y[VPT];
+                gen(x, k);
+                chains(x, y, w0, w1, warm_tag);
+                to_tile(y, tile + k * CC * kTileStride + lane);
+            }
+            n_cur += R;
+            if (have) flush_finish(pend, pend_row, R);
+            flush_issue(pend);
+            pend_row = first; first += R; have = true;
+        }
+        if (have) flush_finish(pend, pend_row, R);
+        while (done < count) single();
     };
-    walk(0, c, std::false_type{});
-    walk(c, total, std::true_type{});
+    auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag) {
+        if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{});
+        else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{});
+    };
+
+    walk_any(c0, 0, z0, z1, std::false_type{}, std::false_type{});             // warm-up of the span's first block
+    for (int bi = 0; bi < nb; ++bi) {
+        const int64_t orow = (b_first + bi) * a.N;
+        const int tail = (bi + 1 < nb) ? a.ctx : 0;                            // rows that also warm the next block up (N >= ctx)
+        walk_any(a.N - tail, orow, z0, z1, std::true_type{}, std::false_type{});
+        if (tail) {
+            double w0[VPT], w1[VPT];                                           // the next block's chain, from zero state
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) { w0[i] = 0.0; w1[i] = 0.0; }
+            walk_any(tail, orow + a.N - tail, w0, w1, std::true_type{}, std::true_type{});
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) { z0[i] = w0[i]; z1[i] = w1[i]; }
+        }
+    }
+    if (BUS && staged) flush_now();
 }
 
 template <int C>
@@ -308,36 +363,57 @@ __global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restr
     }
 }
 
-// Voices per lane: 4 amortises the per-row scalar work best, but a lane walks its rows serially, so when the
-// launch is small (latency mode: one block) spread the voices over more waves instead of fewer, longer ones.
-int pick_vpt(int voices, int64_t nblocks) {
-    const char* e = getenv("SIG_FUSED_VPT");
-    if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
-    for (int vpt = 4; vpt > 1; vpt >>= 1) {
-        const int64_t waves = ((voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt)) * nblocks;
-        if (waves >= 1024) return vpt;                                         // one wave per SIMD or more
+int env_int(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+// Launch geometry (tools/sweep_fused.sh).  Voices per lane: 4 amortises the per-row work shared by a lane's voices
+// (bus staging, loop control) best and leaves room for two waves per SIMD.  Blocks per lane (span): the first
+// block of a span pays a c-row warm-up that computes the oscillator only for the filter, so longer spans waste
+// less -- but a lane walks its rows serially and one wave per SIMD cannot keep the f64 pipe busy, so the span
+// only grows while the launch still has two waves per SIMD; and in the latency regime (one block, few voices)
+// the voices are spread over more, shorter waves instead.
+constexpr int64_t kWavesWanted = 2048;     // two waves per SIMD
+
+void pick_geometry(const FusedArgs& a, int max_vpt, int& vpt, int& span) {
+    const int env_vpt = env_int("SIG_FUSED_VPT"), env_span = env_int("SIG_FUSED_SPAN");   // tuning / test hooks
+    const int max_span = (a.N >= a.ctx) ? 8 : 1;
+    auto waves = [&](int v, int s) { return (int64_t)((a.voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((a.K + s - 1) / s); };
+    vpt = max_vpt; span = max_span;
+    while (span > 1 && waves(vpt, span) < kWavesWanted) span >>= 1;
+    while (vpt > 1 && waves(vpt, 1) < kWavesWanted / 2) vpt >>= 1;
+    if (env_vpt == 1 || env_vpt == 2 || env_vpt == 4) vpt = (env_vpt <= max_vpt) ? env_vpt : max_vpt;
+    if (env_span >= 1) span = (env_span <= max_span) ? env_span : max_span;
+}
+
+template <int KIND, bool GAIN, int C>
+int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
+{
+    a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+    const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    switch (vpt) {
+        case 1: fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 2: fused_walk_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 4: fused_walk_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        default: return (int)hipErrorInvalidValue;
     }
-    return 1;
+    return sig_launch_status();
 }
 
 template <int KIND, bool GAIN, int C>
 int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
-    const int vpt = pick_vpt(a.voices, a.K);
-    a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
-    const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
-    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    switch (vpt) {
-        case 1: fused_voice_bus_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 2: fused_voice_bus_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        default: fused_voice_bus_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-    }
-    int err = sig_launch_status();
+    int vpt;
+    pick_geometry(a, 4, vpt, a.span);
+    int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
     if (err) return err;
+    const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t n = bus.rows * C;
     int64_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
-    bus_partials_kernel<C><<<(unsigned)g, 256, 0, stream>>>(bus.partials, a.voice_tiles, bus.rows, out, out_ld);
+    bus_partials_kernel<C><<<(unsigned)g, 256, 0, stream>>>(bus.partials, tiles, bus.rows, out, out_ld);
     return sig_launch_status();
 }
 
@@ -345,9 +421,11 @@ template <int KIND, bool GAIN>
 int dispatch_bus_channels(int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
 {
     switch (C) {
+#ifndef SIG_TUNE_SINE_ONLY
         case 1: return launch_voice_bus<KIND, GAIN, 1>(a, bus, out, out_ld, s);
-        case 2: return launch_voice_bus<KIND, GAIN, 2>(a, bus, out, out_ld, s);
         case 4: return launch_voice_bus<KIND, GAIN, 4>(a, bus, out, out_ld, s);
+#endif
+        case 2: return launch_voice_bus<KIND, GAIN, 2>(a, bus, out, out_ld, s);
     }
     return (int)hipErrorInvalidValue;
 }
@@ -357,9 +435,11 @@ int dispatch_bus_kind(int kind, int C, const FusedArgs& a, const BusArgs& bus, f
 {
     switch (kind) {
         case SIG_OSC_SINE: return dispatch_bus_channels<SIG_OSC_SINE, GAIN>(C, a, bus, out, out_ld, s);
+#ifndef SIG_TUNE_SINE_ONLY
         case SIG_OSC_SQUARE: return dispatch_bus_channels<SIG_OSC_SQUARE, GAIN>(C, a, bus, out, out_ld, s);
         case SIG_OSC_SAWTOOTH: return dispatch_bus_channels<SIG_OSC_SAWTOOTH, GAIN>(C, a, bus, out, out_ld, s);
         case SIG_OSC_TRIANGLE: return dispatch_bus_channels<SIG_OSC_TRIANGLE, GAIN>(C, a, bus, out, out_ld, s);
+#endif
     }
     return (int)hipErrorInvalidValue;
 }
@@ -454,12 +534,6 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(FusedArgs a)
     }
 }
 
-int pick_vpt(int voices, int64_t nblocks);
-
-int fused_variant() {
-    static int v = [] { const char* e = getenv("SIG_FUSED_VPT"); return e ? atoi(e) : 0; }();
-    return v;
-}
 
 // chains below which the serial walk leaves most of the chip idle (one wave per SIMD = 65536 lanes)
 constexpr int64_t kScanMaxChains = 16384;
@@ -468,7 +542,8 @@ template <int KIND, bool GAIN>
 int launch_fused(FusedArgs a, hipStream_t stream)
 {
     {
-        static const int scan_env = [] { const char* e = getenv("SIG_FUSED_SCAN"); return e ? atoi(e) : -1; }();
+        const char* scan_str = getenv("SIG_FUSED_SCAN");                      // tuning / test hook
+        const int scan_env = scan_str ? atoi(scan_str) : -1;
         const int64_t chains = (int64_t)a.voices * a.K;
         const bool fits = a.ctx + a.N <= kScanMaxL * SIG_WAVE;
         const bool want = scan_env >= 0 ? scan_env != 0 : chains <= kScanMaxChains;
@@ -482,20 +557,11 @@ int launch_fused(FusedArgs a, hipStream_t stream)
     auto ok = [&](int vpt) {
         return (a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0);
     };
-    int vpt = fused_variant() ? fused_variant() : pick_vpt(a.voices, a.K);
-    while (vpt > 1 && !ok(vpt)) vpt >>= 1;
-    if (!ok(vpt)) vpt = 1;
-    const int span = SIG_WAVE * vpt;
-    a.voice_tiles = (a.voices + span - 1) / span;
-    const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
-    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    switch (vpt) {
-        case 1: fused_osc_biquad_kernel<KIND, 1, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
-        case 2: fused_osc_biquad_kernel<KIND, 2, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
-        case 4: fused_osc_biquad_kernel<KIND, 4, GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a); break;
-        default: return (int)hipErrorInvalidValue;
-    }
-    return sig_launch_status();
+    int max_vpt = 4;
+    while (max_vpt > 1 && !ok(max_vpt)) max_vpt >>= 1;
+    int vpt;
+    pick_geometry(a, max_vpt, vpt, a.span);
+    return launch_walk<KIND, GAIN, 0>(a, BusArgs{nullptr, 0, nullptr, 0}, vpt, stream);
 }
 
 template <bool GAIN>
@@ -503,9 +569,11 @@ int dispatch_kind(int kind, const FusedArgs& a, hipStream_t s)
 {
     switch (kind) {
         case SIG_OSC_SINE: return launch_fused<SIG_OSC_SINE, GAIN>(a, s);
+#ifndef SIG_TUNE_SINE_ONLY
         case SIG_OSC_SQUARE: return launch_fused<SIG_OSC_SQUARE, GAIN>(a, s);
         case SIG_OSC_SAWTOOTH: return launch_fused<SIG_OSC_SAWTOOTH, GAIN>(a, s);
         case SIG_OSC_TRIANGLE: return launch_fused<SIG_OSC_TRIANGLE, GAIN>(a, s);
+#endif
     }
     return (int)hipErrorInvalidValue;
 }

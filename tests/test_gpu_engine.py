@@ -596,7 +596,8 @@ def test_ringmod_with_adsr_in_one_pass():
     torch.cuda.synchronize()
     names = set(timer.summary())
     assert 'adsr_apply' in names and 'biquad_coldstart[lp,env]' not in names, names
-    assert np.array_equal(got, stream(fx_mix(*(lambda b: (b.input.sig, b.input.sig.left.sig))(c3_graph(V)[0])), 0, N, K, V))
+    # the inner Saw -> LowPass pair runs fused (f64 oscillator samples): rounding-level agreement with the eager path
+    assert maxerr(got, stream(fx_mix(*(lambda b: (b.input.sig, b.input.sig.left.sig))(c3_graph(V)[0])), 0, N, K, V)) < 1e-6
 
 
 def fx_mix(a, b):
