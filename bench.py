@@ -37,7 +37,18 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8
 ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
               'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
               'fused_voice_bus': 2 * 2 * 8 / 256 + 2 * 4 / 1024}   # f64 tile partials (written, re-read) + f32 stereo bus
-F64_INSTR_PER_UPDATE = {'fused_osc_biquad': 12, 'fused_voice_bus': 13}   # f64-rate VALU instructions per (voice, row), ISA count
+FUSED_KERNELS = ('fused_osc_biquad', 'fused_voice_bus')
+
+
+def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2):
+    """f64-rate VALU instructions per stored voice-sample of the fused Sine walker, counted in the ISA
+    (DESIGN.md §4): 2 for the oscillator recurrence on every row a lane walks (span*N + c rows per span*N stored),
+    4 for the b0-normalised DF2T on (N + c)/N rows (every block is warmed up c rows), then per stored row either
+    C bus FMAs + C/vpt adds of the cross-lane flush (16 adds per lane per 16/C rows), or 1 multiply + 1 conversion for the f32 store"""
+    from signals_amd import _native
+    vpt, span = _native.fused_geometry(voices, N, K, ctx)
+    sink = bus_channels + bus_channels / vpt if name == 'fused_voice_bus' else 2.0
+    return 2.0 * (span * N + ctx) / (span * N) + 4.0 * (N + ctx) / N + sink, vpt, span
 
 
 def synth_params(total_voices: int):
@@ -241,16 +252,15 @@ def main():
                                'traffic': traffic,
                                'algo_bytes_per_voice_sample': kernels[dom]['algo_bytes_per_voice_sample'],
                                'avg_launch_ms': kernels[dom]['avg_ms']}
-            if dom.split('[')[0] in F64_INSTR_PER_UPDATE:
+            if dom.split('[')[0] in FUSED_KERNELS:
                 # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
-                # the meaningful ceiling is the f64 vector issue rate.  f64-rate instructions per (voice, row) update,
-                # counted in the ISA: 4 phase (fast Sine path) + 2 cvt + 5 fused DF2T + 2 bus FMAs (or
-                # 1 gain mul); (N+c)/N updates per stored sample (context rows are recomputed);
+                # the meaningful ceiling is the f64 vector issue rate,
                 # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
-                upd = (summ[dom]['units'] / summ[dom]['calls']) * (N + 100) / N
-                ach = F64_INSTR_PER_UPDATE[dom.split('[')[0]] * upd / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
+                ops, vpt, span = fused_f64_ops_per_voice_sample(dom.split('[')[0], V, N, K)
+                ach = ops * (summ[dom]['units'] / summ[dom]['calls']) / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
                 res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
-                                               'frac': ach / 39.3}
+                                               'frac': ach / 39.3, 'f64_ops_per_voice_sample': ops,
+                                               'voices_per_lane': vpt, 'blocks_per_lane': span}
                 res['roofline']['note'] = ('this kernel is f64-VALU-bound, not HBM-bound: see valu_f64; the HBM-bound '
                                            'node-materialised schedule is reported under alt_schedule')
             res['kernels'] = kernels

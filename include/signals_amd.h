@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 2
+#define SIG_ABI_VERSION 3
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -195,6 +195,11 @@ int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
  * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second
  * kernel adds the tiles in a fixed order and rounds to f32.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
+/* Introspection: the launch geometry the two fused entry points use for this problem size -- voices per lane
+ * (1, 2 or 4) and consecutive blocks per lane (the span walker, fused_voice.hip).  For measurement tools (the
+ * f64 operation count per voice-sample depends on the span) and tests; no device work. */
+int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context,
+                       int32_t* voices_per_lane, int32_t* blocks_per_lane);
 int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,

@@ -24,7 +24,8 @@ STATUS_BAD_CUTOFF = 1
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
-           'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env')
+           'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
+           'sig_fused_geometry')
 
 
 class NativeError(RuntimeError):
@@ -92,7 +93,9 @@ def lib() -> ctypes.CDLL:
                                                vp, i64, i64, vp, i64, vp, vp]
         L.sig_advance_position.restype = ctypes.c_int
         L.sig_advance_position.argtypes = [vp, i64, vp]
-        if L.sig_abi_version() != 2:
+        L.sig_fused_geometry.restype = ctypes.c_int
+        L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        if L.sig_abi_version() != 3:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
     return _lib
@@ -332,6 +335,14 @@ def fused_osc_biquad(kind: str, btype: str, rate: int, position, block_frames: i
                                       status.data_ptr() if status is not None else None, _stream(out)),
            'sig_fused_osc_biquad')
     return out
+
+
+def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -> tuple[int, int]:
+    """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
+    vpt, span = ctypes.c_int32(), ctypes.c_int32()
+    _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
+           'sig_fused_geometry')
+    return vpt.value, span.value
 
 
 def advance_position(position: torch.Tensor, delta: int) -> None:

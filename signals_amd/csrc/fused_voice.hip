@@ -629,6 +629,19 @@ extern "C" int sig_advance_position(int64_t* position_dev, int64_t delta, void* 
     return sig_launch_status();
 }
 
+extern "C" int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context,
+                                  int32_t* voices_per_lane, int32_t* blocks_per_lane)
+{
+    SIG_CHECK_ARG(voices >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices_per_lane && blocks_per_lane);
+    FusedArgs a{};
+    a.N = block_frames; a.K = nblocks; a.ctx = context; a.voices = voices;
+    int vpt = 1, span = 1;
+    pick_geometry(a, 4, vpt, span);
+    *voices_per_lane = vpt;
+    *blocks_per_lane = span;
+    return 0;
+}
+
 extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)
 {
     // worst case: one tile per 64 voices (VPT = 1)

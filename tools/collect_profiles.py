@@ -16,14 +16,16 @@ import shutil
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-FAMILY = {'fused_osc_biquad_kernel': 'fused_osc_biquad', 'fused_voice_bus_kernel': 'fused_voice_bus',
+# fused_walk_kernel is both fused entry points (template argument C = 0: f32 store, C > 0: bus); the C2 bench only
+# launches the bus form
+FAMILY = {'fused_walk_kernel': 'fused_voice_bus',
           'bus_partials_kernel': 'bus_partials', 'sum_bus_fast_kernel': 'sum_bus', 'sum_bus_kernel': 'sum_bus',
           'osc_bank_kernel': 'osc_bank', 'biquad_coldstart_kernel': 'biquad_coldstart',
           'biquad_walk_kernel': 'biquad_coldstart', 'ew_fast_kernel': 'elementwise', 'fused_scan_kernel': 'fused_scan'}
 
 
 def load(tag, mode, ctr):
-    f = glob.glob(str(ROOT / f'gpurun_out/pmc{tag}_{mode}_{ctr}/runc/*_counter_collection.csv'))[0]
+    f = glob.glob(str(ROOT / f'gpurun_out/pmc{tag}_{mode}_{ctr}/*/*_counter_collection.csv'))[0]
     acc = collections.defaultdict(list)
     rows = []
     for row in csv.DictReader(open(f)):
@@ -54,7 +56,7 @@ def main(tag, rnd):
                                     extrasaction='ignore')
                 w_.writeheader()
                 w_.writerows(rows)
-        src = glob.glob(str(ROOT / f'gpurun_out/stats{tag}_{mode}/runc/*_kernel_stats.csv'))[0]
+        src = glob.glob(str(ROOT / f'gpurun_out/stats{tag}_{mode}/*/*_kernel_stats.csv'))[0]
         shutil.copy(src, ROOT / f'profiles/{rnd}_{mode}_kernel_stats.csv')
         shutil.copy(ROOT / f'gpurun_out/stats{tag}_{mode}.json', ROOT / f'profiles/{rnd}_{mode}_bench_under_rocprof.json')
     if 'fused_voice_bus' in out and 'bus_partials' in out:
