@@ -71,6 +71,8 @@ struct FusedArgs {
     float* out; int64_t out_ld; int voice_tiles; int* status;
     const int64_t* pos_dev = nullptr;        // when set, the position is read from device memory (hipGraph replay)
     int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
+    int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
+    const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
 };
 
 // Bus: partial[tile][row][c] = sum over the wave's 64*VPT voices of pan[c][v] * gain[v] * y[v].  Lanes are
@@ -94,6 +96,13 @@ __device__ __forceinline__ double sin2pi(double f) {
     return __hiloint2double(__double2hiint(y) ^ (int)(((unsigned)__double2loint(u) & 1u) << 31), __double2loint(y));
 }
 
+struct M2 { double a, b, c, d; };                                             // [[a, b], [c, d]]
+__device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
+    return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
+}
+
+__device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb);   // below
+
 // C == 0: store (float)(weight * y) to a.out; C > 0: C bus channels into bus.partials
 template <int KIND, int VPT, bool GAIN, int C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
@@ -116,6 +125,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     const int vc = live0 ? v0 : 0;
 
     const int64_t p0 = (a.pos_dev ? *a.pos_dev : a.position) + b_first * a.N;  // first frame of the span's first block
+    if (BUS && KIND == SIG_OSC_SINE && a.steady && steady_wave(a, v0, VPT, p0, nb)) return;   // fused_steady_bus_kernel's wave
     const int c0 = (int)((p0 < (int64_t)a.ctx) ? p0 : (int64_t)a.ctx);
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
 
@@ -351,6 +361,216 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     if (BUS && staged) flush_now();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Sine through a cold-started LTI filter in closed form ("steady" kernel).  For x_n = sin(phi_n), phi_n = phi_0 +
+// n theta, the filter's response from zero state at row r0 is the steady-state sinusoid plus a decaying
+// homogeneous solution:
+//     y_n = yss_n + yh_n,     yss_n = Im(H(e^{j theta}) e^{j phi_n}),     (z0h, z1h)_n = A (z0h, z1h)_{n-1},  yh_n = z0h_{n-1}
+// with the homogeneous state at r0 - 1 equal to minus the steady-state DF2T state there (so the total state is
+// zero, fx.py:104's sosfilt start).  Every ingredient is linear in (yss_n, yss_{n+1} - yss_n), so the homogeneous
+// state at a block's first row p = r0 + c is one per-voice 2x2 matrix applied to the steady-state oscillator's
+// state at p:   (z0h, z1h)_{p-1} = T_c (yss_p, dss_p),   T_c = -A^c Mss(c)   -- no warm-up rows at all.
+// Per stored sample: 2 (yss recurrence, difference form) + 2 (homogeneous recurrence) + 1 (sum) + C (bus) f64
+// ops instead of 2 (N+c')/N + 4 (N+c)/N + C.  Mathematically identical to the walker; rounding differs at 1e-14.
+// A wave takes this path when every voice of it passes steady_ok(); the other waves are done by the walker
+// launched right after (each kernel skips the other's waves, both test the same predicate).
+// Per-voice constants, computed once per launch by steady_prep_kernel into the tail of the workspace (SoA, kSteadyConsts
+// rows of `voices` doubles): the filter, the oscillator step, H(e^{j theta}) and T_c for c = ctx and for the
+// launch's first block (c = min(ctx, position)).
+enum { SC_NA1, SC_NA2, SC_SCALE, SC_NM, SC_ST, SC_GR, SC_HRE, SC_HIM, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
+
+// per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^24 cycles over
+// the span (as for the walker's Sine recurrence), at most a quarter turn per row, and sin(theta) not tiny (the map
+// from (yss, dss) back to the complex amplitude divides by it: below ~8 Hz at 48 kHz the walker is used instead)
+__device__ __forceinline__ bool steady_voice_ok(double hz, double ph, double rate, double st, double q_first, double q_last) {
+    const double t_first = q_first * hz + ph, t_last = q_last * hz + ph;
+    const double d = hz / rate;
+    const double dr = d - rint(d);
+    return fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT && fabs(dr) <= 0.25 &&
+           fabs(st) >= 1e-3;
+}
+
+// does the steady kernel take the wave of voices [v0, v0 + vpt) x 64 lanes for the span starting at frame p0?
+__device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb) {
+    const double q_first = (double)p0 / a.rate, q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
+    bool ok = true;
+    for (int i = 0; i < vpt; ++i) {
+        const int v = (v0 + i < a.voices) ? v0 + i : ((v0 < a.voices) ? v0 : 0);
+        ok &= steady_voice_ok(a.hertz[(int64_t)v * a.hs], a.phase ? a.phase[(int64_t)v * a.ps] : 0.0, a.rate,
+                              a.steady_consts[(int64_t)SC_ST * a.voices + v], q_first, q_last);
+    }
+    return __all(ok);
+}
+
+template <bool GAIN>
+__global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* __restrict__ consts)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.voices) return;
+    using sig_biquad::Cx; using sig_biquad::cx_mul; using sig_biquad::cx_div;
+    Biquad q;
+    const bool ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
+    if (!ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
+    const double a1 = q.a1, a2 = q.a2;
+    const double d = a.hertz[(int64_t)v * a.hs] / a.rate;
+    const double dr = d - rint(d);
+    const double st = sin2pi(dr), ct = sin2pi(dr + 0.25), sh = sin2pi(0.5 * dr);
+    const Cx z = {ct, -st};                                                    // e^{-j theta}
+    const Cx z2 = cx_mul(z, z);
+    const Cx H = cx_div({1.0 + s2 * z.re + z2.re, s2 * z.im + z2.im}, {1.0 + a1 * z.re + a2 * z2.re, a1 * z.im + a2 * z2.im});
+    const Cx P = {H.re - 1.0, H.im};                                           // z0ss_{n-1} = Im(P u_n)
+    const Cx Pe = cx_mul(P, {ct, st});
+    const Cx Q = {Pe.re - s2 + a1 * H.re, Pe.im + a1 * H.im};                  // z1ss_{n-1} = Im(Q u_n)
+    const double alpha = 2.0 * sh * sh / st, beta = 1.0 / st;                  // wr = alpha yss + beta dss, wi = yss
+    auto make_T = [&](int c) {                                                 // T_c = -A^c Mss(c)
+        const double cf = (double)c * dr;                                      // c theta in revolutions
+        const Cx E = cx_div({sin2pi(cf + 0.25), -sin2pi(cf)}, H);              // e^{-j c theta} / H
+        const Cx PE = cx_mul(P, E), QE = cx_mul(Q, E);
+        const M2 Mss = {fma(PE.im, alpha, PE.re), PE.im * beta, fma(QE.im, alpha, QE.re), QE.im * beta};
+        M2 Ac = {1.0, 0.0, 0.0, 1.0}, Ap = {-a1, 1.0, -a2, 0.0};               // A^c by squaring
+        for (int e = c; e > 0; e >>= 1) {
+            if (e & 1) Ac = m2_mul(Ac, Ap);
+            Ap = m2_mul(Ap, Ap);
+        }
+        const M2 t = m2_mul(Ac, Mss);
+        return M2{-t.a, -t.b, -t.c, -t.d};
+    };
+    const M2 T = make_T(a.ctx);
+    const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
+    const M2 T0 = (c0 == a.ctx) ? T : make_T(c0);
+    auto put = [&](int k, double x) { consts[(int64_t)k * a.voices + v] = x; };
+    put(SC_NA1, -a1); put(SC_NA2, -a2);
+    put(SC_SCALE, GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0);
+    put(SC_NM, -4.0 * sh * sh); put(SC_ST, st); put(SC_GR, -2.0 * sh * sh);
+    put(SC_HRE, H.re); put(SC_HIM, H.im);
+    put(SC_T + 0, T.a); put(SC_T + 1, T.b); put(SC_T + 2, T.c); put(SC_T + 3, T.d);
+    put(SC_T0 + 0, T0.a); put(SC_T0 + 1, T0.b); put(SC_T0 + 2, T0.c); put(SC_T0 + 3, T0.d);
+}
+
+template <int VPT, int C>
+__global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
+{
+    constexpr int R = kPairs / C;          // rows per flush
+    __shared__ double lds[4][kPairs * kTileStride];
+    const int lane = threadIdx.x & 63;
+    double* tile = lds[threadIdx.x >> 6];
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int vt = (int)(item % a.voice_tiles);
+    const int64_t b_first = (item / a.voice_tiles) * a.span;
+    if (b_first >= a.K) return;                                               // wave-uniform
+    const int nb = (int)((a.K - b_first < (int64_t)a.span) ? a.K - b_first : (int64_t)a.span);
+    const int v0 = (vt * SIG_WAVE + lane) * VPT;
+    const int vc = (v0 < a.voices) ? v0 : 0;
+    const int64_t p0 = a.position + b_first * a.N;
+    if (!steady_wave(a, v0, VPT, p0, nb)) return;                             // the walker does this wave
+    const double* sc = a.steady_consts;
+
+    double na1[VPT], na2[VPT], nm[VPT], yss[VPT], dss[VPT], wt[C][VPT];
+    const double q_first = (double)p0 / a.rate;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const bool live = v0 + i < a.voices;
+        const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
+        auto cst = [&](int k) { return sc[(int64_t)k * a.voices + v]; };
+        na1[i] = cst(SC_NA1); na2[i] = cst(SC_NA2); nm[i] = cst(SC_NM);
+        const double scale = cst(SC_SCALE);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0 on the bus
+            wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0;
+        // steady-state oscillator at the span's first row: w = H e^{j phi}, yss = Im w, dss = Im(w (e^{j theta} - 1))
+        const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+        const double t_first = q_first * hz + ph;                              // osc.py:32
+        const double f0 = t_first - rint(t_first);                             // exact, |f0| <= 0.5
+        const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
+        const double hre = cst(SC_HRE), him = cst(SC_HIM);
+        const double wr = fma(hre, ur, -(him * ui)), wi = fma(hre, ui, him * ur);
+        yss[i] = wi;
+        dss[i] = fma(wr, cst(SC_ST), wi * cst(SC_GR));
+    }
+
+    double* dstp = bus.partials + (int64_t)vt * bus.rows * C;                  // [tile][row][c]
+    const double* col = tile + (lane & (kPairs - 1)) * kTileStride + (lane >> 4) * 16;
+    int staged = 0;
+    double* slot = tile + lane;
+    int64_t first = b_first * a.N;
+
+    auto flush_issue = [&](double (&pv)[16]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[k] = col[k];
+    };
+    auto flush_finish = [&](const double (&pv)[16], int64_t row0, int nrows) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += pv[k];
+        s += sig_shfl_xor_f64(s, 16);
+        s += sig_shfl_xor_f64(s, 32);
+        if (lane < nrows * C) dstp[row0 * C + lane] = s;
+    };
+    auto flush_now = [&]() {
+        double pv[16];
+        flush_issue(pv);
+        flush_finish(pv, first, staged);
+        first += staged;
+        staged = 0;
+        slot = tile + lane;
+    };
+
+    double z0h[VPT], z1h[VPT];
+    auto row = [&](double* where) {                                            // one row of every voice into the tile
+        double y[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            y[i] = yss[i] + z0h[i];
+            const double yh = z0h[i];
+            z0h[i] = fma(na1[i], yh, z1h[i]);
+            z1h[i] = na2[i] * yh;
+            yss[i] += dss[i];
+            dss[i] = fma(nm[i], yss[i], dss[i]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) acc = fma(wt[ch][i], y[i], acc);
+            where[ch * kTileStride] = acc;
+        }
+    };
+
+    for (int bi = 0; bi < nb; ++bi) {
+        // homogeneous state at the block's first row; only the launch's very first block can have a short context
+        const int tk = (b_first + bi == 0) ? SC_T0 : SC_T;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = (v0 + i < a.voices) ? v0 + i : vc;
+            const double* t = sc + (int64_t)tk * a.voices + v;
+            z0h[i] = fma(t[0], yss[i], t[a.voices] * dss[i]);
+            z1h[i] = fma(t[2 * (int64_t)a.voices], yss[i], t[3 * (int64_t)a.voices] * dss[i]);
+        }
+        int done = 0;
+        auto single = [&]() {
+            row(slot);
+            slot += C * kTileStride;
+            ++done;
+            if (++staged == R) flush_now();
+        };
+        while (staged != 0 && done < a.N) single();
+        double pend[16];
+        int64_t pend_row = 0;
+        bool have = false;
+        for (; done + R <= a.N; done += R) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) row(tile + k * C * kTileStride + lane);
+            if (have) flush_finish(pend, pend_row, R);
+            flush_issue(pend);
+            pend_row = first; first += R; have = true;
+        }
+        if (have) flush_finish(pend, pend_row, R);
+        while (done < a.N) single();
+    }
+    if (staged) flush_now();
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restrict__ partials, int tiles, int64_t rows,
                                                            float* __restrict__ out, int64_t out_ld)
@@ -361,6 +581,11 @@ __global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restr
         for (int t = 0; t < tiles; ++t) s += partials[(int64_t)t * n + i];       // fixed order
         out[(i / C) * out_ld + (i % C)] = (float)s;
     }
+}
+
+// workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
+int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
+    return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
 }
 
 int env_int(const char* name) {
@@ -407,6 +632,26 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
 {
     int vpt;
     pick_geometry(a, 4, vpt, a.span);
+    if (KIND == SIG_OSC_SINE && (a.N >= a.ctx || a.position >= a.ctx)) {      // at most the first block has a short context
+        // closed-form waves first, then the walker for the waves that do not qualify (each kernel skips the other's)
+        const char* e = getenv("SIG_FUSED_STEADY");                            // tuning / test hook
+        a.steady = e ? atoi(e) : 1;
+        if (a.steady) {
+            double* consts = bus.partials + steady_consts_offset(a.voices, bus.rows, C);
+            a.steady_consts = consts;
+            steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+            a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+            const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
+            if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+            switch (vpt) {
+                case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+                case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+                default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            }
+            const int e2 = sig_launch_status();
+            if (e2) return e2;
+        }
+    }
     int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
     if (err) return err;
     const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
@@ -457,10 +702,6 @@ int dispatch_bus_kind(int kind, int C, const FusedArgs& a, const BusArgs& bus, f
 // the serial kernels to ~1e-13 (f64), not bit for bit.
 constexpr int kScanMaxL = 8;                                                  // rows per lane: c + N <= 512
 
-struct M2 { double a, b, c, d; };                                             // [[a, b], [c, d]]
-__device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
-    return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
-}
 
 template <int KIND, bool GAIN>
 __global__ __launch_bounds__(256) void fused_scan_kernel(FusedArgs a)
@@ -644,9 +885,7 @@ extern "C" int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t 
 
 extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)
 {
-    // worst case: one tile per 64 voices (VPT = 1)
-    const int64_t tiles = (voices + SIG_WAVE - 1) / SIG_WAVE;
-    return tiles * rows * bus_channels * (int64_t)sizeof(double);
+    return (steady_consts_offset(voices, rows, bus_channels) + (int64_t)kSteadyConsts * voices) * (int64_t)sizeof(double);
 }
 
 extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,

@@ -21,14 +21,15 @@ def _device():
     from signals_amd import runtime
     runtime.set_device('cuda:0')
     yield
-    for k in ('SIG_FUSED_VPT', 'SIG_FUSED_SPAN', 'SIG_FUSED_SCAN'):
+    for k in ('SIG_FUSED_VPT', 'SIG_FUSED_SPAN', 'SIG_FUSED_SCAN', 'SIG_FUSED_STEADY'):
         os.environ.pop(k, None)
 
 
-def geometry(vpt, span):
+def geometry(vpt, span, steady=1):
     os.environ['SIG_FUSED_VPT'] = str(vpt)
     os.environ['SIG_FUSED_SPAN'] = str(span)
     os.environ['SIG_FUSED_SCAN'] = '0'                       # the serial walker, not the latency-mode scan kernel
+    os.environ['SIG_FUSED_STEADY'] = str(steady)             # Sine + bus: closed-form kernel for the waves that qualify
 
 
 def dev(a):
@@ -181,3 +182,52 @@ def test_bad_cutoff_is_nan_and_flagged_in_every_geometry():
         bad = np.isnan(got).all(axis=0)
         assert bad[5] and bad[100] and bad.sum() == 2
         assert int(status.item()) & _native.STATUS_BAD_CUTOFF
+
+
+@pytest.mark.parametrize('btype', ['lp', 'hp'])
+@pytest.mark.parametrize('pos', [0, 37, 100, 5000, 172_800_000 // 64])
+def test_closed_form_sine_kernel_matches_the_walker_and_the_oracle(btype, pos):
+    """sig_fused_voice_bus on Sine voices: steady-state sinusoid + homogeneous transient per block (no warm-up rows)
+    against the row-by-row walker (SIG_FUSED_STEADY=0) and the oracle; first contexts of 0, 37 and 100 rows"""
+    V, N, K = 200, 256, 5
+    p = params(V, 20 + pos % 7)
+    ref_bus = oracle_chain('Sine', btype, p, pos, N, K) @ p['pan'].T
+    for vpt, span in GEOMETRIES:
+        geometry(vpt, span, steady=0)
+        walker = run_bus('Sine', btype, p, pos, N, K)
+        geometry(vpt, span, steady=1)
+        steady = run_bus('Sine', btype, p, pos, N, K)
+        assert np.isfinite(steady).all()
+        assert maxerr(steady, walker) < 5e-7, (vpt, span)                # sums of 200 voices, up to +-2: two float32 ulps
+        assert maxerr(steady, f32(ref_bus)) < 2e-6, (vpt, span)
+
+
+def test_closed_form_kernel_leaves_unqualified_waves_to_the_walker():
+    """per-wave choice: voices below ~8 Hz (sin(theta) < 1e-3), above rate/4, or past 2^24 cycles keep their whole
+    wave on the walker; the bus is the sum of both kernels' partial tiles"""
+    V, N, K = 256, 256, 6
+    p = params(V, 30)
+    p['hertz'][0, 3] = 2.0                                   # wave 0 at vpt=1: walker
+    p['hertz'][0, 70] = 20000.0                              # wave 1: walker (exact phase)
+    p['hertz'][0, 130] = 0.0                                 # wave 2: walker
+    ref_bus = oracle_chain('Sine', 'lp', p, 512, N, K) @ p['pan'].T
+    for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 8)]:
+        geometry(vpt, span, steady=1)
+        assert maxerr(run_bus('Sine', 'lp', p, 512, N, K), f32(ref_bus)) < 2e-6, (vpt, span)
+    hour = 172_800_000
+    ref_bus = oracle_chain('Sine', 'lp', p, hour, N, 2) @ p['pan'].T
+    geometry(1, 2, steady=1)
+    assert maxerr(run_bus('Sine', 'lp', p, hour, N, 2), f32(ref_bus)) < 2e-6
+
+
+def test_closed_form_kernel_block_sizes_and_bus_widths():
+    V = 64
+    p = params(V, 31)
+    p['pan'] = np.random.default_rng(32).uniform(-1, 1, (4, V))
+    for N, K in [(100, 6), (64, 5), (1024, 3), (17, 9)]:
+        ref = oracle_chain('Sine', 'lp', p, 0, N, K)
+        for C in (1, 2, 4):
+            want = f32(ref @ p['pan'][:C].T) if C > 1 else f32(ref.sum(axis=1, keepdims=True))
+            for span in (1, 4):
+                geometry(1, span, steady=1)
+                assert maxerr(run_bus('Sine', 'lp', p, 0, N, K, C=C), want) < 1e-6, (N, K, C, span)
