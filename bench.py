@@ -40,14 +40,29 @@ ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus':
 FUSED_KERNELS = ('fused_osc_biquad', 'fused_voice_bus')
 
 
-def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2):
-    """f64-rate VALU instructions per stored voice-sample of the fused Sine walker, counted in the ISA
-    (DESIGN.md §4): 2 for the oscillator recurrence on every row a lane walks (span*N + c rows per span*N stored),
-    4 for the b0-normalised DF2T on (N + c)/N rows (every block is warmed up c rows), then per stored row either
-    C bus FMAs + C/vpt adds of the cross-lane flush (16 adds per lane per 16/C rows), or 1 multiply + 1 conversion for the f32 store"""
+def steady_applies(p, lo, hi, first_frame, last_frame, N, ctx=100):
+    """host mirror of fused_voice.hip:steady_voice_ok for every voice of the shard: does sig_fused_voice_bus run its
+    closed-form Sine kernel (steady-state sinusoid + homogeneous transient) rather than the row-by-row walker?"""
+    hz, ph = p['hertz'][0, lo:hi], p['phase'][0, lo:hi]
+    d = hz / RATE
+    dr = d - np.rint(d)
+    t = np.abs(np.stack([first_frame / RATE * hz + ph, last_frame / RATE * hz + ph]))
+    return bool((t < 2.0 ** 24).all() and (np.abs(dr) <= 0.25).all() and (np.abs(np.sin(2 * np.pi * dr)) >= 1e-3).all()
+                and (N >= ctx or first_frame >= ctx))
+
+
+def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2, steady=False):
+    """f64-rate VALU instructions per stored voice-sample of the fused Sine kernels, counted in the ISA.
+    Walker: 2 for the oscillator recurrence on every row a lane walks (span*N + c rows per span*N stored), 4 for
+    the b0-normalised DF2T on (N + c)/N rows (every block is warmed up c rows).  Closed form (`steady`): 2 for the
+    steady-state recurrence, 2 for the homogeneous one, 1 to add them, no warm-up rows.  Then per stored row either
+    C bus FMAs + C/vpt adds of the cross-lane flush (16 adds per lane per 16/C rows), or 1 multiply + 1 conversion
+    for the f32 store."""
     from signals_amd import _native
     vpt, span = _native.fused_geometry(voices, N, K, ctx)
     sink = bus_channels + bus_channels / vpt if name == 'fused_voice_bus' else 2.0
+    if steady and name == 'fused_voice_bus':
+        return 5.0 + sink, vpt, span
     return 2.0 * (span * N + ctx) / (span * N) + 4.0 * (N + ctx) / N + sink, vpt, span
 
 
@@ -150,9 +165,12 @@ def cpu_baseline_sharded(p, voices, frames, workers, blocks=128):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--blocks', type=int, default=1024, help='256-frame blocks per batch (one step)')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--prewarm-ms', type=float, default=250.0,
+                    help='untimed: keep rendering batches for this long before the W warm-up steps, so that the GPU clocks '
+                         'have settled under load (the first ~50 ms after idle run 15-30 % slower); 0 disables')
+    ap.add_argument('--blocks', type=int, default=4096, help='256-frame blocks per batch (one step)')
     ap.add_argument('--voices', type=int, default=1024, help='voices per GPU')
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--position', type=int, default=0)
@@ -209,6 +227,18 @@ def main():
             pending = work
             return bus
 
+        if args.prewarm_ms > 0:                              # untimed, same work: clocks ramp up under load
+            fence()
+            t_pre = time.perf_counter()
+            for _ in range(4):
+                step()
+            fence()
+            t4 = torch.tensor([time.perf_counter() - t_pre], dtype=torch.float64, device='cuda')
+            if world > 1:
+                dist.all_reduce(t4, op=dist.ReduceOp.MAX)   # the same step count on every rank (one reduce per step)
+            for _ in range(int(min(100000, args.prewarm_ms * 1e-3 / max(float(t4.item()) / 4, 1e-6)))):
+                step()
+            pos = args.position                             # the timed stream starts where it says
         for _ in range(warmup):
             step()
         if pending is not None:
@@ -256,11 +286,20 @@ def main():
                 # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
                 # the meaningful ceiling is the f64 vector issue rate,
                 # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
-                ops, vpt, span = fused_f64_ops_per_voice_sample(dom.split('[')[0], V, N, K)
+                closed = fuse and steady_applies(params, rank * V, (rank + 1) * V, args.position,
+                                                 args.position + (warmup + steps) * N * K - 1, N)
+                ops, vpt, span = fused_f64_ops_per_voice_sample(dom.split('[')[0], V, N, K, steady=closed)
                 ach = ops * (summ[dom]['units'] / summ[dom]['calls']) / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
                 res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
                                                'frac': ach / 39.3, 'f64_ops_per_voice_sample': ops,
-                                               'voices_per_lane': vpt, 'blocks_per_lane': span}
+                                               'voices_per_lane': vpt, 'blocks_per_lane': span,
+                                               'path': 'closed form: steady-state sinusoid + homogeneous transient per '
+                                                       'block, no warm-up rows (fused_steady_bus_kernel)' if closed
+                                                       else 'span walker (fused_walk_kernel)'}
+                res['roofline']['launches'] = ('avg_launch_ms brackets everything sig_fused_voice_bus enqueues: per-voice '
+                                               'constants (steady_prep_kernel), the chain kernel, the walker pass for waves '
+                                               'that do not qualify, and the tile sum (bus_partials_kernel); the chain '
+                                               "kernel's own duration is in profiles/*_kernel_stats.csv")
                 res['roofline']['note'] = ('this kernel is f64-VALU-bound, not HBM-bound: see valu_f64; the HBM-bound '
                                            'node-materialised schedule is reported under alt_schedule')
             res['kernels'] = kernels

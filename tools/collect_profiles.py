@@ -16,10 +16,12 @@ import shutil
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-# fused_walk_kernel is both fused entry points (template argument C = 0: f32 store, C > 0: bus); the C2 bench only
-# launches the bus form
-FAMILY = {'fused_walk_kernel': 'fused_voice_bus',
-          'bus_partials_kernel': 'bus_partials', 'sum_bus_fast_kernel': 'sum_bus', 'sum_bus_kernel': 'sum_bus',
+# one sig_fused_voice_bus call = steady_prep_kernel + fused_steady_bus_kernel + fused_walk_kernel (the waves the closed
+# form does not take; template argument C = 0 is the other entry point's f32 store, not launched by the C2 bench)
+# + bus_partials_kernel: their bytes are summed into 'fused_voice_bus'
+FUSED_CALL = ('fused_steady_bus_kernel', 'fused_walk_kernel', 'steady_prep_kernel', 'bus_partials_kernel')
+FAMILY = {'fused_walk_kernel': 'fused_voice_bus', 'fused_steady_bus_kernel': 'fused_voice_bus', 'steady_prep_kernel': 'fused_voice_bus',
+          'bus_partials_kernel': 'fused_voice_bus', 'sum_bus_fast_kernel': 'sum_bus', 'sum_bus_kernel': 'sum_bus',
           'osc_bank_kernel': 'osc_bank', 'biquad_coldstart_kernel': 'biquad_coldstart',
           'biquad_walk_kernel': 'biquad_coldstart', 'ew_fast_kernel': 'elementwise', 'fused_scan_kernel': 'fused_scan'}
 
@@ -48,7 +50,10 @@ def main(tag, rnd):
             f = sum(fe[k][1:]) / len(fe[k][1:])
             w = sum(wr[k][1:]) / len(wr[k][1:])
             raw[f'{mode}/{k}'] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'launches': len(fe[k])}
-            out[FAMILY[k]] = out.get(FAMILY[k], 0) * 0 + int((2 * f + w) * 1024)
+            if k in FUSED_CALL:
+                out[FAMILY[k]] = out.get(FAMILY[k], 0) + int((2 * f + w) * 1024)
+            else:
+                out[FAMILY[k]] = int((2 * f + w) * 1024)
         for ctr, rows in (('FETCH_SIZE', fe_rows), ('WRITE_SIZE', wr_rows)):
             with open(ROOT / f'profiles/{rnd}_{mode}_pmc_{ctr}.csv', 'w', newline='') as fh:
                 w_ = csv.DictWriter(fh, fieldnames=['Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count',
@@ -59,8 +64,6 @@ def main(tag, rnd):
         src = glob.glob(str(ROOT / f'gpurun_out/stats{tag}_{mode}/*/*_kernel_stats.csv'))[0]
         shutil.copy(src, ROOT / f'profiles/{rnd}_{mode}_kernel_stats.csv')
         shutil.copy(ROOT / f'gpurun_out/stats{tag}_{mode}.json', ROOT / f'profiles/{rnd}_{mode}_bench_under_rocprof.json')
-    if 'fused_voice_bus' in out and 'bus_partials' in out:
-        out['fused_voice_bus'] += out.pop('bus_partials')        # one C-ABI call = both launches
     bench = json.loads((ROOT / f'gpurun_out/stats{tag}_fused.json').read_text())
     cfg = bench['config']
     out['_meta'] = {
