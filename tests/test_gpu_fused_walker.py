@@ -231,3 +231,21 @@ def test_closed_form_kernel_block_sizes_and_bus_widths():
             for span in (1, 4):
                 geometry(1, span, steady=1)
                 assert maxerr(run_bus('Sine', 'lp', p, 0, N, K, C=C), want) < 1e-6, (N, K, C, span)
+
+
+def test_closed_form_kernel_one_second_blocks_and_extreme_cutoffs():
+    """N = 48000 (the homogeneous part decays to nothing long before the block ends; the steady recurrence runs
+    96 000 rows from one seed) and cutoffs from 5 Hz to 23.9 kHz (poles next to the unit circle / next to -1)"""
+    V, N, K = 64, 48000, 2
+    p = params(V, 50)
+    p['cutoff'][0, :] = np.geomspace(5.0, 23900.0, V)
+    ref = oracle_chain('Sine', 'lp', p, 0, N, K)
+    ref_bus = ref @ p['pan'].T
+    for steady in (1, 0):
+        geometry(1, 2, steady=steady)
+        got = run_bus('Sine', 'lp', p, 0, N, K)
+        assert np.isfinite(got).all()
+        assert maxerr(got, f32(ref_bus)) < 1e-6, steady
+    ref = oracle_chain('Sine', 'hp', p, 4800, 256, 4) @ p['pan'].T
+    geometry(2, 2, steady=1)
+    assert maxerr(run_bus('Sine', 'hp', p, 4800, 256, 4), f32(ref)) < 1e-6
