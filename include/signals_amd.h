@@ -97,6 +97,20 @@ int sig_biquad_coldstart_env(int type, int32_t rate, int64_t position,
                              const float* in, int64_t in_ld, int64_t in_history,
                              float* out, int64_t out_ld, int32_t* status, void* stream);
 
+/* Filter [x envelope] summed straight into the bus: out[n,c] = sum_v bus_gains[c,v] * env[n,v] * Filter(in)[n,v]
+ * -- SumBus(Filter(x)) or SumBus(RingMod(Filter(x), ADSR)) (fx.py:85-121, fx.py:43-46, the build-defined bus) in
+ * one pass over `in`; nothing per-voice is written.  adsr_params == NULL: no envelope.  bus_gains == NULL:
+ * bus_channels == 1, plain sum.  `workspace`: device, at least sig_fused_voice_bus_workspace(voices, rows,
+ * bus_channels) bytes (per-voice-tile f64 partials, added in a fixed order by a second launch).  Buffers as in
+ * sig_biquad_coldstart (float32 only). */
+int sig_biquad_coldstart_bus(int type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* cutoff, int32_t cutoff_stride, int32_t cutoff_blocks,
+                             const double* const* adsr_params, const int32_t* adsr_strides,
+                             const float* in, int64_t in_ld, int64_t in_history,
+                             const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                             double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* BandPass / BandStop done right (the reference's DoubleCritFilter raises TypeError at
  * fx.py:99, its intent being butter(N=2, Wn=[low, high], btype='bp'|'bs', output='sos') + sosfilt):
  * two biquad sections in series, designed in closed form per voice, same cold-start block semantics and

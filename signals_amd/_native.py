@@ -25,7 +25,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
-           'sig_fused_geometry')
+           'sig_fused_geometry', 'sig_biquad_coldstart_bus')
 
 
 class NativeError(RuntimeError):
@@ -93,6 +93,10 @@ def lib() -> ctypes.CDLL:
                                                vp, i64, i64, vp, i64, vp, vp]
         L.sig_advance_position.restype = ctypes.c_int
         L.sig_advance_position.argtypes = [vp, i64, vp]
+        L.sig_biquad_coldstart_bus.restype = ctypes.c_int
+        L.sig_biquad_coldstart_bus.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, i32,
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                                               vp, i64, i64, vp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_geometry.restype = ctypes.c_int
         L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
         if L.sig_abi_version() != 3:
@@ -337,11 +341,55 @@ def fused_osc_biquad(kind: str, btype: str, rate: int, position, block_frames: i
     return out
 
 
+def biquad_coldstart_bus(btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                         cutoff: torch.Tensor, buf: torch.Tensor, history: int, bus_gains: torch.Tensor | None,
+                         out: torch.Tensor, envelope: dict | None = None, workspace: torch.Tensor | None = None,
+                         status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (nblocks*block_frames, C) f32 <- sum over voices of bus_gains * [envelope *] Filter(buf); `buf` holds
+    `history` context rows followed by the input rows, like `biquad_coldstart`; `envelope`: ADSR control rows"""
+    _gpu(cutoff, buf, out, status, bus_gains, *(envelope or {}).values())
+    _audio(buf, 'biquad bus in')
+    _audio(out, 'biquad bus out')
+    rows, bus = out.shape
+    voices = buf.shape[1]
+    if out.dtype != torch.float32 or buf.dtype != torch.float32 or rows != block_frames * nblocks or buf.shape[0] != history + rows:
+        raise NativeError(f'biquad bus shapes: in {tuple(buf.shape)} {buf.dtype} history {history} out {tuple(out.shape)} {out.dtype}')
+    if cutoff.dtype != torch.float64 or cutoff.shape[1] not in (1, voices) or cutoff.shape[0] not in (1, nblocks) \
+            or not cutoff.is_contiguous():
+        raise NativeError(f'cutoff must be contiguous float64 (1|{nblocks}, 1|{voices}), got {tuple(cutoff.shape)} {cutoff.dtype}')
+    gp, gld = None, 0
+    if bus_gains is not None:
+        if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus, voices) or bus_gains.stride(1) != 1:
+            raise NativeError(f'bus gains must be float64 ({bus},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+        gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+    elif bus != 1:
+        raise NativeError('a bus without gains is mono')
+    ptrs = strides = None
+    if envelope is not None:
+        ptrs = (ctypes.c_void_p * 6)()
+        strides = (ctypes.c_int32 * 6)()
+        for i, name in enumerate(ADSR_PARAMS):
+            ptrs[i], strides[i] = _ctrl_row(envelope[name], name)
+            if envelope[name].shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {envelope[name].shape[1]} channels for {voices} voices')
+    need = lib().sig_fused_voice_bus_workspace(voices, rows, bus)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    in_ptr = buf.data_ptr() + history * buf.stride(0) * buf.element_size()
+    _check(lib().sig_biquad_coldstart_bus(FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
+                                          cutoff.data_ptr(), 0 if cutoff.shape[1] == 1 else 1, cutoff.shape[0],
+                                          ptrs, strides, in_ptr, buf.stride(0), history, gp, gld, bus,
+                                          workspace.data_ptr(), out.data_ptr(), out.stride(0),
+                                          status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_biquad_coldstart_bus')
+    return out
+
+
 def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -> tuple[int, int]:
     """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
     vpt, span = ctypes.c_int32(), ctypes.c_int32()
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
-           'sig_fused_geometry')
+           'sig_fused_geometry', 'sig_biquad_coldstart_bus')
     return vpt.value, span.value
 
 

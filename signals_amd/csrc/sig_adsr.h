@@ -7,15 +7,22 @@ namespace sig_env {
 
 struct AdsrRows { const double* p[6]; int s[6]; };   // attack, decay, sustain, release, gate_on, gate_off
 
-__device__ __forceinline__ double clip01(double x) { return (x < 0.0) ? 0.0 : ((x > 1.0) ? 1.0 : x); }
+// clip(x, 0, 1) as two full-rate instructions (v_max_f64, v_min_f64) instead of two compares and two 64-bit selects.
+// Same value as np.clip for every non-NaN x (a NaN envelope parameter is outside the definition).
+__device__ __forceinline__ double clip01(double x) { return fmin(fmax(x, 0.0), 1.0); }
 
-struct Voice { double ia, id, sm1, ir, on, off, attack, hold_off; };
+// Per-voice constants.  The "a zero-length stage counts as complete" cases of the definition are folded into
+// constants so that the per-row code has no select for them:
+//   attack == 0: ia = 0 and the attack value is never chosen (u >= 0 implies v = u - 0 >= 0);
+//   decay == 0:  id = 0, d_bias = 1  ->  clip(fma(v, 0, 1)) = 1;   decay > 0: d_bias = 0 and fma(v, id, 0) == v * id;
+//   release == 0: ir = 0, rel_bias = 0  ->  clip(0 - w * 0) = 0;   release > 0: rel_bias = 1  ->  clip(1 - w * ir).
+struct Voice { double ia, id, sm1, ir, on, off, attack, hold_off, d_bias, rel_bias; };
 
 __device__ __forceinline__ double held(const Voice& p, double t) {
     const double u = t - p.on;
     const double v = u - p.attack;
-    const double a = (p.ia > 0.0) ? clip01(u * p.ia) : 1.0;
-    const double d = (p.id > 0.0) ? clip01(v * p.id) : 1.0;
+    const double a = clip01(u * p.ia);
+    const double d = clip01(fma(v, p.id, p.d_bias));
     return (u < 0.0) ? 0.0 : ((v < 0.0) ? a : 1.0 + p.sm1 * d);
 }
 
@@ -29,6 +36,8 @@ __device__ __forceinline__ Voice load_voice(const AdsrRows& in, int v) {
     p.ia = (attack > 0.0) ? 1.0 / attack : 0.0;
     p.id = (decay > 0.0) ? 1.0 / decay : 0.0;
     p.ir = (release > 0.0) ? 1.0 / release : 0.0;
+    p.d_bias = (decay > 0.0) ? 0.0 : 1.0;
+    p.rel_bias = (release > 0.0) ? 1.0 : 0.0;
     p.sm1 = sustain - 1.0;
     p.hold_off = held(p, p.off);
     return p;
@@ -37,7 +46,7 @@ __device__ __forceinline__ Voice load_voice(const AdsrRows& in, int v) {
 // envelope level at time t (seconds)
 __device__ __forceinline__ double level(const Voice& p, double t) {
     const double w = t - p.off;
-    const double rel = (p.ir > 0.0) ? clip01(1.0 - w * p.ir) : 0.0;
+    const double rel = clip01(p.rel_bias - w * p.ir);
     return (w < 0.0) ? held(p, t) : p.hold_off * rel;
 }
 

@@ -460,6 +460,20 @@ class _Batch:
             self._own_history(node, cols, hist, result)
         return result
 
+    def _enveloped_filter(self, node, channels):
+        """RingMod(filter, ADSR) where nothing else reads the envelope or the filter and the filter's rows are not
+        in the batch yet: (filter, ADSR control rows), else None"""
+        for env_port, x_port in ((node.right, node.left), (node.left, node.right)):
+            env, flt = env_port.sig, x_port.sig
+            if (isinstance(env, ext.ADSR) and env.get_state().enabled and len(env.outputs_with_ports) == 1
+                    and not _modulated(env) and isinstance(flt, fx.SingleCritFilter) and flt.get_state().enabled
+                    and len(flt.outputs_with_ports) == 1 and (flt, channels) not in self._memo):
+                ctl = env.control_rows(lambda bound: self._control_const(bound, bound.name))
+                voices = broadcast_shape((1, 1), *(r.shape for r in ctl.values()))[1]
+                if voices in (1, channels):
+                    return flt, ctl
+        return None
+
     def _ringmod_with_envelope(self, node, channels, hist, rows):
         """RingMod(x, ADSR) with an envelope nobody else reads: the envelope multiplies x on the fly -- in the
         epilogue of the filter that produces x when nothing else reads that filter (sig_biquad_coldstart_env),
@@ -497,11 +511,44 @@ class _Batch:
                 gains = (gains * g) if gains is not None else g.expand(1, voices).contiguous()
                 src_port = top.left
                 self._require(src_port.sig, voices, hist)
+        fused = self._bus_over_filter(node, src_port, gains, hist, rows) if o.fuse and hist == 0 else None
+        if fused is not None:
+            return fused
         x = self._operand(src_port, src_port.channels, hist)
         if x.shape[0] == 1:
             raise NotBatchable('SumBus over a one-row input')
         result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
         return o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+    def _bus_over_filter(self, node, src_port, gains, hist, rows):
+        """SumBus(Filter(x)) / SumBus(RingMod(Filter(x), ADSR)) with no other reader of the filter (and of the
+        RingMod and the envelope): one pass over x, nothing per-voice stored (sig_biquad_coldstart_bus)"""
+        o, top, voices = self.owner, src_port.sig, src_port.channels
+        if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1 or (top, voices) in self._memo:
+            return None
+        flt, ctl = top, None
+        if isinstance(top, fx.RingMod) and not _modulated(top):
+            found = self._enveloped_filter(top, voices)
+            if found is None:
+                return None
+            flt, ctl = found
+        if not isinstance(flt, fx.SingleCritFilter) or not flt.get_state().enabled or (flt, voices) in self._memo:
+            return None
+        if gains is not None and gains.shape[1] != voices:
+            return None
+        cutoff, window, c0 = self._filter_window(flt, voices)
+        if window.dtype != AUDIO_DTYPE or window.shape[1] != voices:
+            return None
+        result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
+        need = _native.lib().sig_fused_voice_bus_workspace(voices, rows, node.channels) // 8
+        if o._workspace is None or o._workspace.numel() < need:
+            o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
+        btype, status = str(flt.type()), o._status_word(flt)
+        return o._launch(f'biquad_bus[{btype}{",env" if ctl else ""}]',
+                         lambda: _native.biquad_coldstart_bus(btype, self.rate, self.pos, self.N, self.K, CONTEXT, cutoff,
+                                                              window, c0, gains, result, envelope=ctl,
+                                                              workspace=o._workspace, status=status),
+                         units=rows * voices)
 
     def _sched_tap(self, node, channels, hist, rows):
         return self._materialise(node.input.sig, channels)                    # pass-through: same buffer
@@ -559,6 +606,29 @@ class _Batch:
     )
 
     # -------------------------------------------------------------- filters
+    def _filter_window(self, node: fx.CritFilter, channels: int):
+        """(cutoff rows, input window with c0 = min(100, pos) context rows in front, c0) of a single-cutoff filter"""
+        N, K, pos = self.N, self.K, self.pos
+        cutoff = self._control(node.cutoff, 'cutoff')
+        c0 = min(CONTEXT, pos)
+        src = node.input.sig
+        pure_in = _is_pure(src, self._pure)
+        if not pure_in and N <= CONTEXT and (K > 1 or self.continuing):
+            raise NotBatchable('cascaded filters with block size <= 100 depend on the after-window cache entries')
+        window, have = self._materialise(src, channels)
+        if window.shape[0] == 1:
+            raise ValueError('filter input answered a single row (unplugged or disabled input)')
+        window = window[have - c0:] if have != c0 else window
+        if window.shape[1] < channels:
+            raise IndexError(f'index {window.shape[1]} is out of bounds for axis 1 with size {window.shape[1]}')
+        if cutoff.shape[1] < channels:
+            raise IndexError(f'index {cutoff.shape[1]} is out of bounds for axis 1 with size {cutoff.shape[1]}')
+        window = window[:, :channels]
+        cutoff = cutoff[:, :channels]
+        if not cutoff.is_contiguous():
+            cutoff = cutoff.contiguous()
+        return cutoff, window, c0
+
     def _filter(self, node: fx.CritFilter, channels: int, hist: int, rows: int, envelope: dict | None = None,
                 owner_node: Emitter | None = None) -> torch.Tensor:
         """`envelope` / `owner_node`: the filter runs on behalf of RingMod(filter, ADSR) -- its stored rows are
@@ -566,8 +636,20 @@ class _Batch:
         o = self.owner
         N, K, pos = self.N, self.K, self.pos
         band = isinstance(node, fx.DoubleCritFilter)
-        cutoff = self._control_const(node.low, 'low') if band else self._control(node.cutoff, 'cutoff')
-        high = self._control_const(node.high, 'high') if band else None
+        if not band:
+            cutoff, window, c0 = self._filter_window(node, channels)
+            result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=window.device)
+            main = result[hist:]
+            btype = str(node.type())
+            status = o._status_word(node)
+            o._launch(f'biquad_coldstart[{btype}{",env" if envelope else ""}]',
+                      lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
+                                                       status=status, envelope=envelope),
+                      units=N * K * channels)
+            self._own_history(owner_node or node, channels, hist, result)
+            return result
+        cutoff = self._control_const(node.low, 'low')
+        high = self._control_const(node.high, 'high')
         c0 = min(CONTEXT, pos)
         src = node.input.sig
         pure_in = _is_pure(src, self._pure)
@@ -589,22 +671,16 @@ class _Batch:
         main = result[hist:]
         btype = str(node.type())
         status = o._status_word(node)
-        if band:
-            if high.shape[1] < channels:
-                raise IndexError(f'index {high.shape[1]} is out of bounds for axis 1 with size {high.shape[1]}')
-            high = high[:, :channels]
-            if not high.is_contiguous():
-                high = high.contiguous()
-            o._launch(f'band_coldstart[{btype}]',
-                      lambda: _native.band_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, high, window, c0, main,
-                                                     status=status),
-                      units=N * K * channels)
-        else:
-            o._launch(f'biquad_coldstart[{btype}{",env" if envelope else ""}]',
-                      lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
-                                                       status=status, envelope=envelope),
-                      units=N * K * channels)
-        self._own_history(owner_node or node, channels, hist, result)
+        if high.shape[1] < channels:
+            raise IndexError(f'index {high.shape[1]} is out of bounds for axis 1 with size {high.shape[1]}')
+        high = high[:, :channels]
+        if not high.is_contiguous():
+            high = high.contiguous()
+        o._launch(f'band_coldstart[{btype}]',
+                  lambda: _native.band_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, high, window, c0, main,
+                                                 status=status),
+                  units=N * K * channels)
+        self._own_history(node, channels, hist, result)
         return result
 
     def _own_history(self, node: Emitter, channels: int, hist: int, result: torch.Tensor) -> None:

@@ -565,9 +565,10 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
 
 
 def test_ringmod_with_adsr_in_one_pass():
-    """RingMod(Filter, ADSR) -> envelope in the filter's epilogue (sig_biquad_coldstart_env) when neither the
-    envelope nor the filter has another consumer; RingMod(x, ADSR) -> sig_adsr_apply otherwise; C3 stays within
-    1e-6 of the oracle either way"""
+    """SumBus(RingMod(Filter, ADSR)) -> one pass over the filter's input, nothing per-voice stored
+    (sig_biquad_coldstart_bus) when nothing else reads the three nodes; RingMod(Filter, ADSR) read by something
+    else -> envelope in the filter's epilogue (sig_biquad_coldstart_env); filter read twice -> sig_adsr_apply; C3
+    stays within 1e-6 of the oracle every way"""
     from oracle import chain_ref as R
     from signals_amd.chain import ext
     from signals_amd.engine import BatchRenderer, KernelTimer
@@ -580,12 +581,45 @@ def test_ringmod_with_adsr_in_one_pass():
     got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
     torch.cuda.synchronize()
     names = set(timer.summary())
-    assert 'biquad_coldstart[lp,env]' in names and 'adsr_apply' not in names and 'adsr' not in names, names
+    assert 'biquad_bus[lp,env]' in names and not names & {'adsr_apply', 'adsr', 'sum_bus', 'biquad_coldstart[lp,env]'}, names
     assert not any(n.startswith('elementwise[RingMod') for n in names), names
     f2 = R.Filter('lp', R.Filter('lp', o(p), R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
-    ref = R.sum_bus(R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, 2 * K, V))
-    assert maxerr(got, f32(ref)) < 1e-6
+    ref_rm = R.render_stream(R.Binary('RingMod', f2, R.Adsr(**p['env'])), 0, N, 2 * K, V)
+    assert maxerr(got, f32(R.sum_bus(ref_rm))) < 1e-6
     assert maxerr(got, batched(c3_graph(V)[0], 0, N, 2 * K, 1)) < 1e-6
+
+    # the RingMod itself is the sink: its rows must exist, the envelope goes into the filter's epilogue
+    bus, p = c3_graph(V)
+    timer = KernelTimer()
+    r = BatchRenderer(bus.input.sig, V, RATE, timer=timer)
+    got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
+    torch.cuda.synchronize()
+    names = set(timer.summary())
+    assert 'biquad_coldstart[lp,env]' in names and not names & {'adsr_apply', 'adsr', 'biquad_bus[lp,env]'}, names
+    assert maxerr(got, f32(ref_rm)) < 1e-6
+
+    # a stereo bus with gains over a plain filter (no envelope), and a mono bus behind a Gain
+    from signals_amd.chain import fx
+    rng = np.random.default_rng(5)
+    pan = rng.uniform(-1, 1, (2, V))
+    for stereo in (True, False):
+        f1 = fx.HighPass(); f1.input = mkosc('Triangle', p['hertz'], p['phase']); f1.cutoff = fix(p['cut1'])
+        f2n = fx.LowPass(); f2n.input = f1; f2n.cutoff = fix(p['cut2'])
+        top = f2n
+        if not stereo:
+            top = fx.Gain(); top.left = f2n; top.right = fix(p['cut1'] / 8000.0)
+        b = ext.SumBus(); b.input = top
+        if stereo:
+            b.get_state().gains = pan
+        timer = KernelTimer()
+        got = BatchRenderer(b, 2 if stereo else 1, RATE, timer=timer).render(0, N, K).cpu().numpy()
+        torch.cuda.synchronize()
+        assert 'biquad_bus[lp]' in set(timer.summary()) and 'sum_bus' not in set(timer.summary()), set(timer.summary())
+        chain = R.Filter('lp', R.Filter('hp', R.Osc('Triangle', R.Fixed(p['hertz']), R.Fixed(p['phase'])), R.Fixed(p['cut1'])),
+                         R.Fixed(p['cut2']))
+        ref = R.render_stream(chain, 0, N, K, V)
+        want = ref @ pan.T if stereo else (ref * (p['cut1'] / 8000.0)).sum(axis=1, keepdims=True)
+        assert maxerr(got, f32(want)) < 2e-6, stereo
 
     # the filter has a second consumer: its rows must exist un-enveloped, the envelope is applied in one pass
     bus, p = c3_graph(V)

@@ -37,7 +37,7 @@ def c3(V):
         setattr(env, name, fixed(rng.uniform(lo, hi, (1, V))))
     rm = fx.RingMod(); rm.left = f2; rm.right = env
     bus = ext.SumBus(); bus.input = rm
-    return bus, 1, 1024, 256, {'osc_bank': 4, 'biquad_coldstart': 8, 'adsr': 4, 'adsr_apply': 8, 'fused_osc_biquad': 4, 'elementwise': 12, 'sum_bus': 4}
+    return bus, 1, 1024, 256, {'osc_bank': 4, 'biquad_coldstart': 8, 'adsr': 4, 'adsr_apply': 8, 'fused_osc_biquad': 4, 'elementwise': 12, 'sum_bus': 4, 'biquad_bus': 4}
 
 
 def c5(V):
