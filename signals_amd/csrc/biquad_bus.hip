@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
     const int64_t p_b = a.position + b * a.N;
     const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);        // BlockLoc.before: min(ctx, position)
 
-    Biquad q[VPT];
-    double z0[VPT], z1[VPT], w[C][VPT];
+    const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
+    double na1[VPT], na2[VPT], z0[VPT], z1[VPT], w[C][VPT];
     sig_env::Voice ev[ENV ? VPT : 1];
     bool ok = true, any_live = false;
 #pragma unroll
@@ -56,10 +56,12 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
         const int v = live ? v0 + i : vc;
         any_live |= live;
         const double hz = a.cutoff[(a.cutoff_blocks > 1 ? b * (int64_t)(a.cs ? a.voices : 1) : 0) + (int64_t)v * a.cs];
-        ok &= design_butter2(a.type, hz, a.rate, q[i]) || !live;
+        Biquad q;
+        ok &= design_butter2(a.type, hz, a.rate, q) || !live;
+        na1[i] = -q.a1; na2[i] = -q.a2;
         z0[i] = 0.0; z1[i] = 0.0;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) w[ch][i] = live ? (a.pan ? a.pan[ch * a.pan_ld + v] : 1.0) : 0.0;
+        for (int ch = 0; ch < C; ++ch) w[ch][i] = live ? (a.pan ? a.pan[ch * a.pan_ld + v] * q.b0 : q.b0) : 0.0;
         if (ENV) ev[i] = sig_env::load_voice(env, v);
     }
     if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
@@ -87,10 +89,9 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
             ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * a.in_ld);
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
-                // scipy _sosfilt, transposed direct form II, one rounding per op (contract off)
-                y[i] = q[i].b0 * x[i] + z0[i];
-                z0[i] = q[i].b1 * x[i] - q[i].a1 * y[i] + z1[i];
-                z1[i] = q[i].b2 * x[i] - q[i].a2 * y[i];
+                y[i] = x[i] + z0[i];                                           // DF2T of [1, s2, 1] / [1, a1, a2]
+                z0[i] = fma(na1[i], y[i], fma(s2, x[i], z1[i]));
+                z1[i] = fma(na2[i], y[i], x[i]);
             }
             if (ENV) {
                 if ((r & 63) == 0) q_lane = (double)(p_b - c + r + lane) / a.rate;   // n/rate for 64 rows, one per lane

@@ -30,16 +30,15 @@ __device__ __forceinline__ double sig_shfl_xor_f64(double x, int mask) {
     return __hiloint2double(hi, lo);
 }
 
-// numpy's float mod for a positive power-of-two divisor (npy_divmod semantics):
+// numpy's float mod for a positive power-of-two divisor d = 1/INV_D (npy_divmod semantics):
 //   m = fmod(t, d)  (exact);  if (m != 0 && m < 0) m += d (ROUNDED, like numpy);  if (m == 0) m = +0
-// D2 = 1/d must make t*D2 exact, i.e. d in {1, 0.5}.
+// Evaluated as  t - d * floor(t * INV_D):  d * floor(..) is exact, and for t < 0 the one rounded subtraction
+// rounds the same real number (fmod + d) that numpy's rounded addition rounds, so the bits are the same; an exact
+// multiple gives t - t = +0.  Two instructions (v_floor_f64, v_fma_f64 / v_add_f64) and no select.
 template <int INV_D>
 __device__ __forceinline__ double sig_npmod_pow2(double t) {
-    const double d = 1.0 / (double)INV_D;
-    double m = t - d * trunc(t * (double)INV_D);   // exact: the result of fmod is representable
-    if (m < 0.0) m += d;
-    else if (m == 0.0) m = 0.0;                     // -0 -> +0 (copysign(0, d))
-    return m;
+    if (INV_D == 1) return t - floor(t);
+    return fma(floor(t * (double)INV_D), -1.0 / (double)INV_D, t);   // single rounding of the exact t - d * floor
 }
 
 __device__ __forceinline__ double sig_sign(double x) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ double osc_square(double t) {       // osc.py:48-49
 }
 
 __device__ __forceinline__ double osc_sawtooth(double t) {     // osc.py:54-55
-    return 2.0 * sig_npmod_pow2<1>(t - 0.5) - 1.0;
+    return fma(sig_npmod_pow2<1>(t - 0.5), 2.0, -1.0);     // 2m is exact: the same single rounding as 2*m - 1
 }
 
 __device__ __forceinline__ double osc_triangle(double t) {     // osc.py:60-62
