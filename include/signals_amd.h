@@ -203,6 +203,18 @@ int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const
                                 float* out, int64_t out_ld, int32_t* status, void* stream);
 int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
 
+/* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
+ * -- the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going
+ * through HBM: every 32 rows of a 64-voice group are staged as float32 in LDS and multiplied on the matrix cores
+ * (exact-f32 MFMA, same k order as sig_mix_matrix, so the result equals sig_mix_matrix over sig_fused_osc_biquad's
+ * output bit for bit).  voices % 64 == 0; matrix (64, 64) float32 row-major on the device. */
+int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                             const double* cutoff, int32_t cutoff_stride,
+                             const double* gain, int32_t gain_stride,
+                             const float* matrix, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* Fused voice chain + sum bus:  out[n,c] = sum_v bus_gains[c,v] * ([gain[v] *] Filter(Osc)[n,v])
  * (bus_gains == NULL: bus_channels == 1, plain sum).  Nothing per-voice touches HBM.  Two launches inside:
  * the chain kernel writes per-voice-tile f64 partials into `workspace` (device, at least

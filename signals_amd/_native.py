@@ -25,7 +25,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
-           'sig_fused_geometry', 'sig_biquad_coldstart_bus')
+           'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix')
 
 
 class NativeError(RuntimeError):
@@ -97,6 +97,9 @@ def lib() -> ctypes.CDLL:
         L.sig_biquad_coldstart_bus.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, i32,
                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
                                                vp, i64, i64, vp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_osc_biquad_mix.restype = ctypes.c_int
+        L.sig_fused_osc_biquad_mix.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                               dp, i32, dp, i32, dp, i32, dp, i32, vp, vp, i64, vp, vp]
         L.sig_fused_geometry.restype = ctypes.c_int
         L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
         if L.sig_abi_version() != 3:
@@ -389,8 +392,32 @@ def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -
     """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
     vpt, span = ctypes.c_int32(), ctypes.c_int32()
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
-           'sig_fused_geometry', 'sig_biquad_coldstart_bus')
+           'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix')
     return vpt.value, span.value
+
+
+def fused_osc_biquad_mix(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
+                         hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
+                         gain: torch.Tensor | None, matrix: torch.Tensor, out: torch.Tensor,
+                         status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (nblocks*block_frames, voices) f32 <- ([gain *] Filter(Osc)) @ blockdiag(matrix), 64-voice groups"""
+    _gpu(hertz, phase, cutoff, gain, matrix, out, status)
+    _audio(out, 'fused mix out')
+    rows, voices = out.shape
+    if out.dtype != torch.float32 or rows != block_frames * nblocks or voices % 64:
+        raise NativeError(f'fused mix out must be float32 ({block_frames * nblocks}, 64*g), got {tuple(out.shape)} {out.dtype}')
+    if matrix.dtype != torch.float32 or tuple(matrix.shape) != (64, 64) or not matrix.is_contiguous():
+        raise NativeError(f'mix matrix must be contiguous float32 (64, 64), got {tuple(matrix.shape)} {matrix.dtype}')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    _check(lib().sig_fused_osc_biquad_mix(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
+                                          voices, *ptrs, matrix.data_ptr(), out.data_ptr(), out.stride(0),
+                                          status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_fused_osc_biquad_mix')
+    return out
 
 
 def advance_position(position: torch.Tensor, delta: int) -> None:

@@ -70,6 +70,7 @@ struct FusedArgs {
     const double* cutoff; int cs; const double* gain; int gs;
     float* out; int64_t out_ld; int voice_tiles; int* status;
     const int64_t* pos_dev = nullptr;        // when set, the position is read from device memory (hipGraph replay)
+    const float* mix = nullptr;              // C == -1: the (64, 64) row-major mix matrix
     int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
     int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
@@ -81,6 +82,7 @@ struct FusedArgs {
 // 65 doubles: conflict-free for the transposed read) and reduced by lane = pair: 16 LDS reads + 2 shuffles per
 // lane per flush.  A second tiny kernel adds the voice tiles in a fixed order (deterministic, no atomics) and
 // rounds to f32.  Nothing but parameters is read from HBM and nothing but the bus is written.
+constexpr int kMixTileRows = 32, kMixLdsStride = 68;   // MixMatrix sink: rows per MFMA tile, floats per LDS row (64 + 4 pad)
 constexpr int kPairs = 16;                 // (row, channel) pairs reduced per flush
 constexpr int kTileStride = 65;            // doubles
 
@@ -103,18 +105,24 @@ __device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
 
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb);   // below
 
-// C == 0: store (float)(weight * y) to a.out; C > 0: C bus channels into bus.partials
+// C == 0: store (float)(weight * y) to a.out; C > 0: C bus channels into bus.partials; C == -1 (one voice per lane,
+// voices a multiple of 64): the MixMatrix sink -- the wave's 64 voices are one matrix group, every 32 rows of
+// float32 samples are staged in a wave-private LDS tile and multiplied by the 64 x 64 matrix on the matrix cores
+// exactly as mix_matrix.hip does (same fragment layout, same k order, same exact-f32 MFMA), then stored.  The
+// per-voice rows never touch HBM, and the walker's f64 VALU work of one wave overlaps the MFMAs of the other
+// wave on the SIMD.
 template <int KIND, int VPT, bool GAIN, int C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
 void fused_walk_kernel(FusedArgs a, BusArgs bus)
 {
-    constexpr bool BUS = C > 0;
+    constexpr bool BUS = C > 0, MIX = C < 0;
     constexpr int CC = BUS ? C : 1;
     constexpr int R = kPairs / CC;         // rows per flush
+    static_assert(!MIX || VPT == 1, "the MixMatrix sink maps one matrix group to one wave");
     using Vec = typename OutVec<VPT>::type;
-    __shared__ double lds[BUS ? 4 : 1][BUS ? kPairs * kTileStride : 1];
+    __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? kMixTileRows * kMixLdsStride / 2 : 1)];
     const int lane = threadIdx.x & 63;
-    double* tile = lds[BUS ? (threadIdx.x >> 6) : 0];
+    double* tile = lds[(BUS || MIX) ? (threadIdx.x >> 6) : 0];
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
@@ -182,7 +190,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         fast = __all(small);
     }
 
-    float* dst = BUS ? nullptr : a.out + vc;                                   // row index = frame - position
+    float* dst = (BUS || MIX) ? nullptr : a.out + vc;                          // row index = frame - position
     double* dstp = BUS ? bus.partials + (int64_t)vt * bus.rows * C : nullptr;  // [tile][row][c]
     const double* col = tile + (lane & (kPairs - 1)) * kTileStride + (lane >> 4) * 16;   // this lane's 16 values of a flush
     int staged = 0;                                                            // rows in the tile
@@ -214,6 +222,50 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         slot = tile + lane;
     };
 
+    // MixMatrix sink (mix_matrix.hip): B operands M[32h + ks][32 jt + i] in 64 VGPRs, rows staged as float32
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    float* ftile = reinterpret_cast<float*>(tile);
+    float bm[MIX ? 2 : 1][MIX ? 32 : 1];
+    int mstaged = 0;
+    int64_t mrow0 = b_first * a.N;                                             // output row of tile row 0
+    if constexpr (MIX) {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            bm[0][ks] = a.mix[(32 * h + ks) * 64 + i];
+            bm[1][ks] = a.mix[(32 * h + ks) * 64 + 32 + i];
+        }
+    }
+    auto mix_flush = [&](int nrows) {
+        if constexpr (MIX) {
+            const int i = lane & 31, h = lane >> 5;
+            float af[32];                                                      // half-row x[i][32h .. 32h+31]: k(ks, h) = 32h + ks
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(ftile + i * kMixLdsStride + 32 * h + 4 * c);
+                af[4 * c] = t.x; af[4 * c + 1] = t.y; af[4 * c + 2] = t.z; af[4 * c + 3] = t.w;
+            }
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[0][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[1][ks], acc1, 0, 0, 0);
+            }
+            // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+            float* d = a.out + mrow0 * a.out_ld + (int64_t)vt * 64 + i;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (r < nrows) {
+                    d[(int64_t)r * a.out_ld] = acc0[reg];
+                    d[(int64_t)r * a.out_ld + 32] = acc1[reg];
+                }
+            }
+            mrow0 += nrows;
+            mstaged = 0;
+        }
+    };
+
     // one row of the lane's recurrences: y = output of the current block's chain; WARM rows also advance the
     // next block's warm-up chain on the same input
     auto chains = [&](const double (&x)[VPT], double (&y)[VPT], double (&w0)[VPT], double (&w1)[VPT], auto warm_tag) {
@@ -240,6 +292,11 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         }
     };
     auto to_out = [&](const double (&y)[VPT], int64_t out_row) {
+        if constexpr (MIX) {                                                   // rows arrive in order: stage, multiply every 32
+            ftile[mstaged * kMixLdsStride + lane] = (float)(y[0] * wt[0][0]);
+            if (++mstaged == kMixTileRows) mix_flush(kMixTileRows);
+            return;
+        }
         float y32[VPT];
 #pragma unroll
         for (int i = 0; i < VPT; ++i) y32[i] = (float)(y[i] * wt[0][i]);
@@ -359,6 +416,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         }
     }
     if (BUS && staged) flush_now();
+    if (MIX && mstaged) mix_flush(mstaged);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -618,11 +676,15 @@ int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    switch (vpt) {
-        case 1: fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 2: fused_walk_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 4: fused_walk_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        default: return (int)hipErrorInvalidValue;
+    if constexpr (C < 0) {
+        fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus);
+    } else {
+        switch (vpt) {
+            case 1: fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 2: fused_walk_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 4: fused_walk_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            default: return (int)hipErrorInvalidValue;
+        }
     }
     return sig_launch_status();
 }
@@ -805,6 +867,28 @@ int launch_fused(FusedArgs a, hipStream_t stream)
     return launch_walk<KIND, GAIN, 0>(a, BusArgs{nullptr, 0, nullptr, 0}, vpt, stream);
 }
 
+template <int KIND, bool GAIN>
+int launch_mix(FusedArgs a, hipStream_t stream)
+{
+    int vpt;
+    pick_geometry(a, 1, vpt, a.span);                                          // one voice per lane: a wave = one matrix group
+    return launch_walk<KIND, GAIN, -1>(a, BusArgs{nullptr, 0, nullptr, 0}, 1, stream);
+}
+
+template <bool GAIN>
+int dispatch_mix_kind(int kind, const FusedArgs& a, hipStream_t s)
+{
+    switch (kind) {
+        case SIG_OSC_SINE: return launch_mix<SIG_OSC_SINE, GAIN>(a, s);
+#ifndef SIG_TUNE_SINE_ONLY
+        case SIG_OSC_SQUARE: return launch_mix<SIG_OSC_SQUARE, GAIN>(a, s);
+        case SIG_OSC_SAWTOOTH: return launch_mix<SIG_OSC_SAWTOOTH, GAIN>(a, s);
+        case SIG_OSC_TRIANGLE: return launch_mix<SIG_OSC_TRIANGLE, GAIN>(a, s);
+#endif
+    }
+    return (int)hipErrorInvalidValue;
+}
+
 template <bool GAIN>
 int dispatch_kind(int kind, const FusedArgs& a, hipStream_t s)
 {
@@ -868,6 +952,26 @@ extern "C" int sig_advance_position(int64_t* position_dev, int64_t delta, void* 
     SIG_CHECK_ARG(position_dev != nullptr);
     advance_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(position_dev, delta);
     return sig_launch_status();
+}
+
+extern "C" int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                        const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                        const double* cutoff, int32_t cutoff_stride,
+                                        const double* gain, int32_t gain_stride,
+                                        const float* matrix, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && matrix && out && out_ld >= voices && voices % 64 == 0);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                out, out_ld, 0, status};
+    a.mix = matrix;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return gain ? dispatch_mix_kind<true>(osc_kind, a, s) : dispatch_mix_kind<false>(osc_kind, a, s);
 }
 
 extern "C" int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context,

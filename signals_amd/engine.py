@@ -718,7 +718,7 @@ class _VoiceChain:
     # ---- matching
     @classmethod
     def match_and_launch(cls, batch: _Batch, node: Emitter, channels: int, hist: int) -> torch.Tensor | None:
-        bus_node, top = None, node
+        bus_node, mix_node, top = None, None, node
         if isinstance(node, ext.SumBus):
             if not batch.owner.fuse_bus or hist != 0 or node.channels not in (1, 2, 4):
                 return None
@@ -726,6 +726,12 @@ class _VoiceChain:
             if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
                 return None
             channels = node.input.channels
+        elif isinstance(node, ext.MixMatrix):
+            if hist != 0 or channels % 64:
+                return None
+            mix_node, top = node, node.input.sig
+            if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1:
+                return None
         gain_node, filt = None, top
         if isinstance(top, fx.Gain):
             gain_node, filt = top, top.left.sig
@@ -740,6 +746,8 @@ class _VoiceChain:
         controls = chain.resolve()
         if controls is None or not chain.widths_ok(controls):
             return None
+        if mix_node is not None:
+            return chain.launch_mix(mix_node, controls)
         return chain.launch_bus(node, controls) if bus_node is not None else chain.launch_chain(node, controls, hist)
 
     def resolve(self):
@@ -791,6 +799,18 @@ class _VoiceChain:
         if node is o.node:
             o._remember_replay(N, K, replay)
         return run(b.pos, controls, torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev))
+
+    # ---- chain + MixMatrix: out (K*N, voices), the per-voice rows only ever exist as 32-row LDS tiles
+    def launch_mix(self, mix_node, controls) -> torch.Tensor:
+        b, o = self.batch, self.batch.owner
+        N, K, v = b.N, b.K, self.channels
+        out = torch.empty((N * K, v), dtype=AUDIO_DTYPE, device=runtime.device())
+        matrix, status = mix_node.resident_matrix(), o._status_word(self.filt)
+        return o._launch(f'fused_osc_biquad_mix[{self.tag}]',
+                         lambda: _native.fused_osc_biquad_mix(self.kind, self.btype, b.rate, b.pos, N, K, CONTEXT,
+                                                              controls[0], controls[1], controls[2], controls[3], matrix, out,
+                                                              status=status),
+                         units=N * K * v)
 
     # ---- chain + bus: out (K*N, bus channels)
     def launch_bus(self, node: Emitter, controls) -> torch.Tensor:

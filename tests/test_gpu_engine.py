@@ -269,6 +269,15 @@ def test_c5_config_vs_oracle():
     ref = R.mix_matrix(lp, M.astype(np.float32).astype(np.float64))
     assert maxerr(got, f32(ref)) < 2e-6
     assert np.array_equal(got, stream(build(), 0, N, K, V))
+    # engine default: the chain and the matrix in one launch (sig_fused_osc_biquad_mix), mid-stream too
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    timer = KernelTimer()
+    r = BatchRenderer(build(), V, RATE, timer=timer)
+    fused = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, 3).cpu().numpy()])
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'fused_osc_biquad_mix[Sine,lp]'}, set(timer.summary())
+    lp = R.render_stream(R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), R.Fixed(cut)), 0, N, K + 3, V)
+    assert maxerr(fused, f32(R.mix_matrix(lp, M.astype(np.float32).astype(np.float64)))) < 2e-6
 
 
 def test_fused_voice_chain_vs_golden_and_unfused(golden):

@@ -249,3 +249,21 @@ def test_closed_form_kernel_one_second_blocks_and_extreme_cutoffs():
     ref = oracle_chain('Sine', 'hp', p, 4800, 256, 4) @ p['pan'].T
     geometry(2, 2, steady=1)
     assert maxerr(run_bus('Sine', 'hp', p, 4800, 256, 4), f32(ref)) < 1e-6
+
+
+@pytest.mark.parametrize('kind', ['Sine', 'Sawtooth'])
+def test_mix_matrix_sink_equals_mix_matrix_over_the_stored_chain_bit_for_bit(kind):
+    """sig_fused_osc_biquad_mix == sig_mix_matrix(sig_fused_osc_biquad) in every bit (same float32 rows, same MFMA k
+    order), for spans, ragged batch ends (N*K not a multiple of the 32-row MFMA tile) and short first contexts"""
+    from signals_amd import _native
+    rng = np.random.default_rng(60)
+    M = torch.tensor(rng.standard_normal((64, 64)), dtype=torch.float32, device='cuda')
+    for V, N, K, pos, span in [(128, 256, 5, 37, 1), (128, 256, 5, 0, 4), (64, 100, 3, 512, 2), (192, 50, 7, 0, 1), (64, 17, 5, 3, 8)]:
+        p = params(V, 61 + V + N)
+        geometry(1, span)
+        chain = torch.tensor(run_chain(kind, 'lp', p, pos, N, K), device='cuda')
+        want = _native.mix_matrix(chain, M, torch.empty_like(chain)).cpu().numpy()
+        got = torch.full((K * N, V), float('nan'), device='cuda')
+        _native.fused_osc_biquad_mix(kind, 'lp', RATE, pos, N, K, CTX, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
+                                     dev(p['gain']), M, got)
+        assert np.array_equal(got.cpu().numpy(), want), (V, N, K, pos, span)

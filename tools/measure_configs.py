@@ -48,7 +48,7 @@ def c5(V):
     f = fx.LowPass(); f.input = o; f.cutoff = fixed(rng.uniform(200, 8000, (1, V)))
     mm = ext.MixMatrix(); mm.input = f
     mm.get_state().matrix = np.linalg.qr(rng.standard_normal((64, 64)))[0]
-    return mm, V, 256, 64, {'fused_osc_biquad': 4, 'mix_matrix': 8, 'osc_bank': 4, 'biquad_coldstart': 8}
+    return mm, V, 256, 64, {'fused_osc_biquad': 4, 'mix_matrix': 8, 'osc_bank': 4, 'biquad_coldstart': 8, 'fused_osc_biquad_mix': 4}
 
 
 def run(name, build, V, steps=10):
