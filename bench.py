@@ -310,6 +310,26 @@ def main():
     if not args.single_mode:
         other = measure(fuse=args.materialised, steps=max(3, args.steps // 2), warmup=min(2, args.warmup))
 
+    by_batch = None
+    if world == 1 and not args.single_mode and not args.materialised:
+        # the same schedule at smaller batches (BASELINE.md's throughput mode is K = 256), clocks already settled
+        from signals_amd.engine import BatchRenderer
+        by_batch = {}
+        for k in (256, 1024):
+            if k == K:
+                continue
+            r = BatchRenderer(build_graph(params, 0, V), 2, RATE)
+            pos = 0
+            for _ in range(10):
+                r.render(pos, N, k); pos += N * k
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                r.render(pos, N, k); pos += N * k
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 200
+            by_batch[str(k)] = {'Msamples_per_s': V * N * k / dt / 1e6, 'ms_per_step': dt * 1e3}
+
     latency = None
     if world == 1 and not args.single_mode:
         # latency mode: ONE 256-frame block per request, as a real-time sink would pull it
@@ -362,7 +382,12 @@ def main():
                 line[k] = main_mode[k]
         if other is not None:
             other['schedule'] = describe(args.materialised)
+            if not args.materialised:
+                # SURVEY.md 8d's whole-graph view of the per-node schedule: 24 algorithmic bytes per voice-sample
+                other['hbm_frac_at_24_bytes_per_voice_sample'] = other['value'] * 1e6 * 24 / (HBM_PEAK_GBS * 1e9)
             line['alt_schedule'] = other
+        if by_batch:
+            line['fused_schedule_at_other_batch_sizes'] = by_batch
         if latency is not None:
             line['latency_mode'] = latency
         if not args.no_cpu_baseline and world == 1:

@@ -246,6 +246,53 @@ def test_kernels_refuse_cpu_tensors_loudly():
         p.input.request(loc(0, 64, 1))
 
 
+def test_every_native_wrapper_refuses_cpu_tensors():
+    """the product path has no CPU fallback: each ctypes wrapper raises before touching the library"""
+    import torch
+    from signals_amd import _native
+    from signals_amd._native import NativeError
+    row = torch.zeros((1, 64), dtype=torch.float64)
+    audio = torch.zeros((256, 64), dtype=torch.float32)
+    bus = torch.zeros((256, 2), dtype=torch.float32)
+    env = {k: row for k in _native.ADSR_PARAMS}
+    calls = {
+        'osc_bank': lambda: _native.osc_bank('Sine', 0, 48000, row, row, audio),
+        'biquad_coldstart': lambda: _native.biquad_coldstart('lp', 48000, 0, 256, 1, 100, row, audio, 0, audio.clone()),
+        'biquad_coldstart_bus': lambda: _native.biquad_coldstart_bus('lp', 48000, 0, 256, 1, 100, row, audio, 0, None, bus[:, :1],
+                                                                     envelope=env),
+        'fused_osc_biquad': lambda: _native.fused_osc_biquad('Sine', 'lp', 48000, 0, 256, 1, 100, row, row, row, None, audio),
+        'fused_voice_bus': lambda: _native.fused_voice_bus('Sine', 'lp', 48000, 0, 256, 1, 100, 64, row, row, row, row,
+                                                           torch.zeros((2, 64), dtype=torch.float64), bus),
+        'fused_osc_biquad_mix': lambda: _native.fused_osc_biquad_mix('Sine', 'lp', 48000, 0, 256, 1, 100, row, row, row, None,
+                                                                     torch.zeros((64, 64)), audio),
+        'sum_bus': lambda: _native.sum_bus(audio, None, bus[:, :1]),
+        'adsr': lambda: _native.adsr(0, 48000, env, audio),
+        'mix_matrix': lambda: _native.mix_matrix(audio, torch.zeros((64, 64)), audio.clone()),
+    }
+    for name, call in calls.items():
+        with pytest.raises(NativeError, match='no CPU fallback'):
+            call()
+
+
+def test_bench_closed_form_predicate_mirrors_the_kernel():
+    """bench.steady_applies (host) restates fused_voice.hip:steady_voice_ok; it decides which f64 operation count the
+    roofline leg uses"""
+    import bench
+    p = bench.synth_params(1024)
+    assert bench.steady_applies(p, 0, 1024, 0, 110 * 4096 * 256, 256)                 # the bench's own stream
+    assert bench.steady_applies(p, 0, 1024, 172_800_000, 172_800_000 + 4096 * 256, 256)
+    assert not bench.steady_applies(p, 0, 1024, 50, 50 + 64 * 17, 17)                  # N < ctx with a short first context
+    slow = {k: v.copy() for k, v in p.items()}
+    slow['hertz'][0, 5] = 2.0                                                          # |sin theta| < 1e-3
+    assert not bench.steady_applies(slow, 0, 1024, 0, 1000, 256)
+    assert bench.steady_applies(slow, 6, 1024, 0, 1000, 256)                           # ... in another shard
+    fast = {k: v.copy() for k, v in p.items()}
+    fast['hertz'][0, 5] = 13000.0                                                      # more than a quarter turn per row
+    assert not bench.steady_applies(fast, 0, 1024, 0, 1000, 256)
+    far = 2 ** 24 * 48000 // 55 + 48000                                                # 55 Hz voice past 2^24 cycles
+    assert not bench.steady_applies(p, 0, 1024, far * 40, far * 40 + 1000, 256)
+
+
 def test_graph_version_bumps_on_mutation():
     v0 = chain.graph_clock.version
     s = osc.Sine(); f = fixed.Fixed()
