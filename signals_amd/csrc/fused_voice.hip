@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "sig_biquad.h"
+#include "sig_bus_tile.h"
 #include "sig_osc.h"
 
 namespace {
@@ -76,15 +77,10 @@ struct FusedArgs {
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
 };
 
-// Bus: partial[tile][row][c] = sum over the wave's 64*VPT voices of pan[c][v] * gain[v] * y[v].  Lanes are
-// voices, so a row's sum is a cross-lane sum; doing it per row with a butterfly would cost as much as the chain
-// itself, so rows are staged kPairs/C at a time in a wave-private LDS tile [pair = row*C + c][lane] (row stride
-// 65 doubles: conflict-free for the transposed read) and reduced by lane = pair: 16 LDS reads + 2 shuffles per
-// lane per flush.  A second tiny kernel adds the voice tiles in a fixed order (deterministic, no atomics) and
-// rounds to f32.  Nothing but parameters is read from HBM and nothing but the bus is written.
+// Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
+using sig_bus::kPairs;
+using sig_bus::kTileStride;
 constexpr int kMixTileRows = 32, kMixLdsStride = 68;   // MixMatrix sink: rows per MFMA tile, floats per LDS row (64 + 4 pad)
-constexpr int kPairs = 16;                 // (row, channel) pairs reduced per flush
-constexpr int kTileStride = 65;            // doubles
 
 struct BusArgs { const double* pan; int64_t pan_ld; double* partials; int64_t rows; };
 
@@ -192,35 +188,8 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 
     float* dst = (BUS || MIX) ? nullptr : a.out + vc;                          // row index = frame - position
     double* dstp = BUS ? bus.partials + (int64_t)vt * bus.rows * C : nullptr;  // [tile][row][c]
-    const double* col = tile + (lane & (kPairs - 1)) * kTileStride + (lane >> 4) * 16;   // this lane's 16 values of a flush
-    int staged = 0;                                                            // rows in the tile
-    double* slot = tile + lane;                                                // where the next row's sums go
-    int64_t first = b_first * a.N;                                             // output row of the first staged row
+    sig_bus::PipelinedTile<CC> stage(tile, lane, dstp, b_first * a.N);
     int64_t n_cur = p0 - c0;                                                   // absolute frame of the next row
-
-    // flush = transposed read of the tile (16 values per lane) + sum + 2 shuffles + store.  The wave's LDS
-    // operations execute in order, so the reads may be issued right after the last write of a group and consumed
-    // a whole group of rows later (flush_issue / flush_finish), which hides their latency.
-    auto flush_issue = [&](double (&pv)[16]) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) pv[k] = col[k];
-    };
-    auto flush_finish = [&](const double (&pv)[16], int64_t row0, int nrows) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += pv[k];
-        s += sig_shfl_xor_f64(s, 16);
-        s += sig_shfl_xor_f64(s, 32);
-        if (lane < nrows * CC) dstp[row0 * CC + lane] = s;
-    };
-    auto flush_now = [&]() {
-        double pv[16];
-        flush_issue(pv);
-        flush_finish(pv, first, staged);
-        first += staged;
-        staged = 0;
-        slot = tile + lane;
-    };
 
     // MixMatrix sink (mix_matrix.hip): B operands M[32h + ks][32 jt + i] in 64 VGPRs, rows staged as float32
     using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -370,12 +339,11 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             ensure(1);
             gen(x, 0);
             chains(x, y, w0, w1, warm_tag);
-            to_tile(y, slot);
-            slot += CC * kTileStride;
+            to_tile(y, stage.slot);
             ++n_cur; ++done;
-            if (++staged == R) flush_now();
+            stage.advance();
         };
-        while (staged != 0 && done < count) single();                          // until the tile is empty
+        while (stage.staged != 0 && done < count) single();                    // until the tile is empty
         double pend[16];
         int64_t pend_row = 0;
         bool have = false;
@@ -386,14 +354,14 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
                 double x[VPT], y[VPT];
                 gen(x, k);
                 chains(x, y, w0, w1, warm_tag);
-                to_tile(y, tile + k * CC * kTileStride + lane);
+                to_tile(y, stage.at(k));
             }
             n_cur += R;
-            if (have) flush_finish(pend, pend_row, R);
-            flush_issue(pend);
-            pend_row = first; first += R; have = true;
+            if (have) stage.finish(pend, pend_row, R);
+            stage.issue(pend);
+            pend_row = stage.first; stage.first += R; have = true;
         }
-        if (have) flush_finish(pend, pend_row, R);
+        if (have) stage.finish(pend, pend_row, R);
         while (done < count) single();
     };
     auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag) {
@@ -415,7 +383,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             for (int i = 0; i < VPT; ++i) { z0[i] = w0[i]; z1[i] = w1[i]; }
         }
     }
-    if (BUS && staged) flush_now();
+    if (BUS && stage.staged) stage.now();
     if (MIX && mstaged) mix_flush(mstaged);
 }
 
@@ -548,31 +516,7 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
     }
 
     double* dstp = bus.partials + (int64_t)vt * bus.rows * C;                  // [tile][row][c]
-    const double* col = tile + (lane & (kPairs - 1)) * kTileStride + (lane >> 4) * 16;
-    int staged = 0;
-    double* slot = tile + lane;
-    int64_t first = b_first * a.N;
-
-    auto flush_issue = [&](double (&pv)[16]) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) pv[k] = col[k];
-    };
-    auto flush_finish = [&](const double (&pv)[16], int64_t row0, int nrows) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += pv[k];
-        s += sig_shfl_xor_f64(s, 16);
-        s += sig_shfl_xor_f64(s, 32);
-        if (lane < nrows * C) dstp[row0 * C + lane] = s;
-    };
-    auto flush_now = [&]() {
-        double pv[16];
-        flush_issue(pv);
-        flush_finish(pv, first, staged);
-        first += staged;
-        staged = 0;
-        slot = tile + lane;
-    };
+    sig_bus::PipelinedTile<C> stage(tile, lane, dstp, b_first * a.N);
 
     double z0h[VPT], z1h[VPT];
     auto row = [&](double* where) {                                            // one row of every voice into the tile
@@ -607,38 +551,25 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
         }
         int done = 0;
         auto single = [&]() {
-            row(slot);
-            slot += C * kTileStride;
+            row(stage.slot);
             ++done;
-            if (++staged == R) flush_now();
+            stage.advance();
         };
-        while (staged != 0 && done < a.N) single();
+        while (stage.staged != 0 && done < a.N) single();
         double pend[16];
         int64_t pend_row = 0;
         bool have = false;
         for (; done + R <= a.N; done += R) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) row(tile + k * C * kTileStride + lane);
-            if (have) flush_finish(pend, pend_row, R);
-            flush_issue(pend);
-            pend_row = first; first += R; have = true;
+            for (int k = 0; k < R; ++k) row(stage.at(k));
+            if (have) stage.finish(pend, pend_row, R);
+            stage.issue(pend);
+            pend_row = stage.first; stage.first += R; have = true;
         }
-        if (have) flush_finish(pend, pend_row, R);
+        if (have) stage.finish(pend, pend_row, R);
         while (done < a.N) single();
     }
-    if (staged) flush_now();
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void bus_partials_kernel(const double* __restrict__ partials, int tiles, int64_t rows,
-                                                           float* __restrict__ out, int64_t out_ld)
-{
-    const int64_t n = rows * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int t = 0; t < tiles; ++t) s += partials[(int64_t)t * n + i];       // fixed order
-        out[(i / C) * out_ld + (i % C)] = (float)s;
-    }
+    if (stage.staged) stage.now();
 }
 
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
@@ -717,11 +648,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
     int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
     if (err) return err;
     const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
-    const int64_t n = bus.rows * C;
-    int64_t g = (n + 255) / 256;
-    if (g > 4096) g = 4096;
-    bus_partials_kernel<C><<<(unsigned)g, 256, 0, stream>>>(bus.partials, tiles, bus.rows, out, out_ld);
-    return sig_launch_status();
+    return sig_bus::launch_partials<C>(bus.partials, tiles, bus.rows, out, out_ld, stream);
 }
 
 template <int KIND, bool GAIN>

@@ -42,6 +42,48 @@ struct Tile {
     }
 };
 
+// the software-pipelined form of the f64-issue-bound fused kernels (fused_voice.hip): rows are staged either one at a
+// time (`put`, flushing when the tile is full) or in statically unrolled groups of R (`put_at` + `issue` / `finish`):
+// the wave's LDS operations execute in order, so the 16 reads of a flush may be issued right after the group's last
+// write and consumed a whole group of rows later, which hides their latency.
+template <int C>
+struct PipelinedTile {
+    static constexpr int R = kPairs / C;   // rows per flush
+    double* tile; const double* col; double* slot; double* dstp;
+    int lane, staged;                      // rows in the tile (single-row mode)
+    int64_t first;                         // output row of the first staged row
+
+    __device__ __forceinline__ PipelinedTile(double* tile_, int lane_, double* dstp_, int64_t first_row)
+        : tile(tile_), col(tile_ + (lane_ & (kPairs - 1)) * kTileStride + (lane_ >> 4) * 16), slot(tile_ + lane_),
+          dstp(dstp_), lane(lane_), staged(0), first(first_row) {}
+
+    __device__ __forceinline__ void issue(double (&pv)[16]) const {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) pv[k] = col[k];
+    }
+    __device__ __forceinline__ void finish(const double (&pv)[16], int64_t row0, int nrows) const {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += pv[k];
+        s += sig_shfl_xor_f64(s, 16);
+        s += sig_shfl_xor_f64(s, 32);
+        if (lane < nrows * C) dstp[row0 * C + lane] = s;
+    }
+    __device__ __forceinline__ void now() {                                    // flush what is staged, at once
+        double pv[16];
+        issue(pv);
+        finish(pv, first, staged);
+        first += staged;
+        staged = 0;
+        slot = tile + lane;
+    }
+    __device__ __forceinline__ double* at(int k) const { return tile + k * C * kTileStride + lane; }   // row k of a group
+    __device__ __forceinline__ void advance() {                                // single-row mode: one row was written at `slot`
+        slot += C * kTileStride;
+        if (++staged == R) now();
+    }
+};
+
 template <int C>
 static __global__ __launch_bounds__(256) void partials_kernel(const double* __restrict__ partials, int tiles, int64_t rows,
                                                                float* __restrict__ out, int64_t out_ld)

@@ -19,9 +19,9 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 # one sig_fused_voice_bus call = steady_prep_kernel + fused_steady_bus_kernel + fused_walk_kernel (the waves the closed
 # form does not take; template argument C = 0 is the other entry point's f32 store, not launched by the C2 bench)
 # + bus_partials_kernel: their bytes are summed into 'fused_voice_bus'
-FUSED_CALL = ('fused_steady_bus_kernel', 'fused_walk_kernel', 'steady_prep_kernel', 'bus_partials_kernel')
+FUSED_CALL = ('fused_steady_bus_kernel', 'fused_walk_kernel', 'steady_prep_kernel', 'bus_partials_kernel', 'partials_kernel')
 FAMILY = {'fused_walk_kernel': 'fused_voice_bus', 'fused_steady_bus_kernel': 'fused_voice_bus', 'steady_prep_kernel': 'fused_voice_bus',
-          'bus_partials_kernel': 'fused_voice_bus', 'sum_bus_fast_kernel': 'sum_bus', 'sum_bus_kernel': 'sum_bus',
+          'bus_partials_kernel': 'fused_voice_bus', 'partials_kernel': 'fused_voice_bus', 'sum_bus_fast_kernel': 'sum_bus', 'sum_bus_kernel': 'sum_bus',
           'osc_bank_kernel': 'osc_bank', 'biquad_coldstart_kernel': 'biquad_coldstart',
           'biquad_walk_kernel': 'biquad_coldstart', 'ew_fast_kernel': 'elementwise', 'fused_scan_kernel': 'fused_scan'}
 
@@ -32,7 +32,7 @@ def load(tag, mode, ctr):
     rows = []
     for row in csv.DictReader(open(f)):
         name = row['Kernel_Name']
-        if 'anonymous' not in name:
+        if 'anonymous' not in name and 'sig_bus::' not in name:          # our kernels only
             continue
         rows.append(row)
         acc[name.split('::')[1].split('<')[0]].append(float(row['Counter_Value']))
