@@ -392,7 +392,7 @@ def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -
     """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
     vpt, span = ctypes.c_int32(), ctypes.c_int32()
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
-           'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix')
+           'sig_fused_geometry')
     return vpt.value, span.value
 
 

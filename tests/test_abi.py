@@ -49,3 +49,14 @@ def test_argument_errors_do_not_reach_the_device(lib):
     lib.sig_mix_matrix.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     assert lib.sig_mix_matrix(32, 100, 16, 100, 16, 16, 100, None) == inv                        # voices % 64
+
+
+def test_fused_geometry_needs_no_device():
+    """sig_fused_geometry is pure host logic: the bench's f64 operation model calls it"""
+    from signals_amd import _native
+    assert _native.fused_geometry(1024, 256, 4096, 100) == (4, 8)        # bench default: 2048 waves of 4 voices x 8 blocks
+    assert _native.fused_geometry(1024, 256, 1024, 100) == (4, 2)
+    assert _native.fused_geometry(1024, 256, 256, 100) == (4, 1)
+    assert _native.fused_geometry(1024, 64, 4096, 100)[1] == 1          # N < ctx: no spans
+    vpt, span = _native.fused_geometry(1024, 256, 1, 100)                # latency mode: spread the voices
+    assert vpt == 1 and span == 1
