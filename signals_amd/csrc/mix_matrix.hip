@@ -19,6 +19,7 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;     // native vector: loop-carried copies stay in registers
 constexpr int kTileRows = 32;
 constexpr int kGroup = 64;
 constexpr int kLdsStride = 68;                         // floats per LDS row (64 + 4 pad)
@@ -41,23 +42,33 @@ __global__ __launch_bounds__(256) void mix_matrix_kernel(int64_t rows, int group
         b[1][ks] = m[(32 * h + ks) * kGroup + 32 + i];
     }
 
-    const int64_t items = row_tiles * groups;
+    const int items = (int)(row_tiles * groups);
     float* tile = lds[wave];
-    for (int64_t item = (int64_t)blockIdx.x * kWaves + wave; item < items; item += (int64_t)gridDim.x * kWaves) {
-        const int g = (int)(item % groups);
-        const int64_t row0 = (item / groups) * kTileRows;
-        const float* src = x + row0 * x_ld + (int64_t)g * kGroup;
-        // 1. coalesced tile load: instr mm covers rows 4mm .. 4mm+3
-        float4 v[8];
+    // 1. coalesced tile load: instr mm covers rows 4mm .. 4mm+3.  The NEXT tile's loads are issued before this tile's
+    //    MFMAs, so their HBM latency (about as long as the 64 MFMAs) is spent under them.
+    struct Rows8 { f32x4 r[8]; };
+    auto load_tile = [&](int item) {                                           // items < 2^31 (host-checked): 32-bit index math
+        Rows8 v;
+        const int g = item % groups;
+        const int64_t row0 = (int64_t)(item / groups) * kTileRows;
+        const int last = (int)((rows - 1 - row0 < kTileRows - 1) ? rows - 1 - row0 : kTileRows - 1);
+        const float* src = x + row0 * x_ld + g * kGroup + 4 * (lane & 15);
 #pragma unroll
         for (int mm = 0; mm < 8; ++mm) {
-            int64_t r = 4 * mm + (lane >> 4);
-            if (row0 + r >= rows) r = rows - 1 - row0;                          // clamp (tail tile)
-            v[mm] = *reinterpret_cast<const float4*>(src + r * x_ld + 4 * (lane & 15));
+            const int r = (4 * mm + (lane >> 4) < last) ? 4 * mm + (lane >> 4) : last;   // clamp (tail tile)
+            v.r[mm] = *reinterpret_cast<const f32x4*>(src + (int64_t)r * x_ld);
         }
+        return v;
+    };
+    const int stride = (int)gridDim.x * kWaves;
+    int item = (int)blockIdx.x * kWaves + wave;
+    Rows8 v = load_tile(item < items ? item : 0);
+    for (; item < items; item += stride) {
+        const int g = item % groups;
+        const int64_t row0 = (int64_t)(item / groups) * kTileRows;
 #pragma unroll
         for (int mm = 0; mm < 8; ++mm)
-            *reinterpret_cast<float4*>(tile + (4 * mm + (lane >> 4)) * kLdsStride + 4 * (lane & 15)) = v[mm];
+            *reinterpret_cast<f32x4*>(tile + (4 * mm + (lane >> 4)) * kLdsStride + 4 * (lane & 15)) = v.r[mm];
         // wave-private tile: no barrier, only the LDS counter (the compiler waits before the reads)
         // 2. half-row fragments
         float a[32];
@@ -66,6 +77,7 @@ __global__ __launch_bounds__(256) void mix_matrix_kernel(int64_t rows, int group
             const float4 t = *reinterpret_cast<const float4*>(tile + i * kLdsStride + 32 * h + 4 * c);
             a[4 * c] = t.x; a[4 * c + 1] = t.y; a[4 * c + 2] = t.z; a[4 * c + 3] = t.w;
         }
+        v = load_tile(item < items - stride ? item + stride : item);           // prefetch (v has been copied to LDS; the last one re-reads)
         // 3. out tile = A (32 x 64) @ M (64 x 64): two 32-column halves
         f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
@@ -99,6 +111,7 @@ extern "C" int sig_mix_matrix(int64_t rows, int32_t voices, const float* x, int6
     const int groups = voices / kGroup;
     const int64_t row_tiles = (rows + kTileRows - 1) / kTileRows;
     const int64_t items = row_tiles * groups;
+    SIG_CHECK_ARG(items < 0x7fffffffLL);
     int64_t nwg = (items + kWaves - 1) / kWaves;
     // persistent: the register budget (M's 64 B-operand VGPRs + A + accumulators) admits 2 workgroups per CU;
     // launch exactly that many so M is fetched once per wave and every wave strides over many tiles

@@ -606,10 +606,12 @@ class _Batch:
     )
 
     # -------------------------------------------------------------- filters
-    def _filter_window(self, node: fx.CritFilter, channels: int):
-        """(cutoff rows, input window with c0 = min(100, pos) context rows in front, c0) of a single-cutoff filter"""
+    def _filter_window(self, node: fx.CritFilter, channels: int, cutoff: torch.Tensor | None = None):
+        """(cutoff rows, input window with c0 = min(100, pos) context rows in front, c0) of a filter; `cutoff`
+        defaults to the single-cutoff filters' control rows"""
         N, K, pos = self.N, self.K, self.pos
-        cutoff = self._control(node.cutoff, 'cutoff')
+        if cutoff is None:
+            cutoff = self._control(node.cutoff, 'cutoff')
         c0 = min(CONTEXT, pos)
         src = node.input.sig
         pure_in = _is_pure(src, self._pure)
@@ -636,51 +638,28 @@ class _Batch:
         o = self.owner
         N, K, pos = self.N, self.K, self.pos
         band = isinstance(node, fx.DoubleCritFilter)
-        if not band:
-            cutoff, window, c0 = self._filter_window(node, channels)
-            result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=window.device)
-            main = result[hist:]
-            btype = str(node.type())
-            status = o._status_word(node)
-            o._launch(f'biquad_coldstart[{btype}{",env" if envelope else ""}]',
-                      lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
-                                                       status=status, envelope=envelope),
-                      units=N * K * channels)
-            self._own_history(owner_node or node, channels, hist, result)
-            return result
-        cutoff = self._control_const(node.low, 'low')
-        high = self._control_const(node.high, 'high')
-        c0 = min(CONTEXT, pos)
-        src = node.input.sig
-        pure_in = _is_pure(src, self._pure)
-        if not pure_in and N <= CONTEXT and (K > 1 or self.continuing):
-            raise NotBatchable('cascaded filters with block size <= 100 depend on the after-window cache entries')
-        window, have = self._materialise(src, channels)
-        if window.shape[0] == 1:
-            raise ValueError('filter input answered a single row (unplugged or disabled input)')
-        window = window[have - c0:] if have != c0 else window
-        if window.shape[1] < channels:
-            raise IndexError(f'index {window.shape[1]} is out of bounds for axis 1 with size {window.shape[1]}')
-        if cutoff.shape[1] < channels:
-            raise IndexError(f'index {cutoff.shape[1]} is out of bounds for axis 1 with size {cutoff.shape[1]}')
-        window = window[:, :channels]
-        cutoff = cutoff[:, :channels]
-        if not cutoff.is_contiguous():
-            cutoff = cutoff.contiguous()
+        cutoff, window, c0 = self._filter_window(node, channels, self._control_const(node.low, 'low') if band else None)
         result = torch.empty((rows, channels), dtype=AUDIO_DTYPE, device=window.device)
         main = result[hist:]
         btype = str(node.type())
         status = o._status_word(node)
-        if high.shape[1] < channels:
-            raise IndexError(f'index {high.shape[1]} is out of bounds for axis 1 with size {high.shape[1]}')
-        high = high[:, :channels]
-        if not high.is_contiguous():
-            high = high.contiguous()
-        o._launch(f'band_coldstart[{btype}]',
-                  lambda: _native.band_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, high, window, c0, main,
-                                                 status=status),
-                  units=N * K * channels)
-        self._own_history(node, channels, hist, result)
+        if band:
+            high = self._control_const(node.high, 'high')
+            if high.shape[1] < channels:
+                raise IndexError(f'index {high.shape[1]} is out of bounds for axis 1 with size {high.shape[1]}')
+            high = high[:, :channels]
+            if not high.is_contiguous():
+                high = high.contiguous()
+            o._launch(f'band_coldstart[{btype}]',
+                      lambda: _native.band_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, high, window, c0, main,
+                                                     status=status),
+                      units=N * K * channels)
+        else:
+            o._launch(f'biquad_coldstart[{btype}{",env" if envelope else ""}]',
+                      lambda: _native.biquad_coldstart(btype, self.rate, pos, N, K, CONTEXT, cutoff, window, c0, main,
+                                                       status=status, envelope=envelope),
+                      units=N * K * channels)
+        self._own_history(owner_node or node, channels, hist, result)
         return result
 
     def _own_history(self, node: Emitter, channels: int, hist: int, result: torch.Tensor) -> None:
