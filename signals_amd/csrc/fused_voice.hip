@@ -129,7 +129,6 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     const int vc = live0 ? v0 : 0;
 
     const int64_t p0 = (a.pos_dev ? *a.pos_dev : a.position) + b_first * a.N;  // first frame of the span's first block
-    if (BUS && KIND == SIG_OSC_SINE && a.steady && steady_wave(a, v0, VPT, p0, nb)) return;   // fused_steady_bus_kernel's wave
     const int c0 = (int)((p0 < (int64_t)a.ctx) ? p0 : (int64_t)a.ctx);
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
 
@@ -398,8 +397,8 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // state at p:   (z0h, z1h)_{p-1} = T_c (yss_p, dss_p),   T_c = -A^c Mss(c)   -- no warm-up rows at all.
 // Per stored sample: 2 (yss recurrence, difference form) + 2 (homogeneous recurrence) + 1 (sum) + C (bus) f64
 // ops instead of 2 (N+c')/N + 4 (N+c)/N + C.  Mathematically identical to the walker; rounding differs at 1e-14.
-// A wave takes this path when every voice of it passes steady_ok(); the other waves are done by the walker
-// launched right after (each kernel skips the other's waves, both test the same predicate).
+// A wave takes this path when every voice of it passes steady_voice_ok(); the rare other waves run
+// steady_fallback_span inside the same launch.
 // Per-voice constants, computed once per launch by steady_prep_kernel into the tail of the workspace (SoA, kSteadyConsts
 // rows of `voices` doubles): the filter, the oscillator step, H(e^{j theta}) and T_c for c = ctx and for the
 // launch's first block (c = min(ctx, position)).
@@ -474,6 +473,56 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
     put(SC_T0 + 0, T0.a); put(SC_T0 + 1, T0.b); put(SC_T0 + 2, T0.c); put(SC_T0 + 3, T0.d);
 }
 
+// The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^24 cycles), done inside the
+// same launch by the plainest possible code: every block on its own, exact per-row phase (one IEEE divide per row),
+// the b0-normalised recurrence from zero state over [c context rows | block], rows staged one at a time.  Rolled
+// loops and no row groups, so that this path does not set the kernel's register budget; ~4x slower per voice-sample
+// than the closed form, and it saves launching the span walker over every wave just to find nothing to do.
+template <int VPT, int C>
+__device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int vt,
+                                                  int64_t b_first, int nb, int v0)
+{
+    const int vc = (v0 < a.voices) ? v0 : 0;
+    const double* sc = a.steady_consts;
+    const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
+    sig_bus::PipelinedTile<C> stage(tile, lane, bus.partials + (int64_t)vt * bus.rows * C, b_first * a.N);
+#pragma unroll 1
+    for (int bi = 0; bi < nb; ++bi) {
+        const int64_t p_b = a.position + (b_first + bi) * a.N;
+        const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+        double z0[VPT], z1[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) z0[i] = z1[i] = 0.0;
+#pragma unroll 1
+        for (int r = -c; r < a.N; ++r) {
+            const double q = (double)(p_b + r) / a.rate;                       // osc.py:32
+            double acc[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const bool live = v0 + i < a.voices;
+                const int v = live ? v0 + i : vc;
+                const double t = q * a.hertz[(int64_t)v * a.hs] + (a.phase ? a.phase[(int64_t)v * a.ps] : 0.0);
+                const double x = (double)sig_osc::osc_sine_f32(t);
+                const double na1 = sc[(int64_t)SC_NA1 * a.voices + v], na2 = sc[(int64_t)SC_NA2 * a.voices + v];
+                const double y = x + z0[i];
+                z0[i] = fma(na1, y, fma(s2, x, z1[i]));
+                z1[i] = fma(na2, y, x);
+                const double scale = live ? sc[(int64_t)SC_SCALE * a.voices + v] : 0.0;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) acc[ch] = fma(bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale, y, acc[ch]);
+            }
+            if (r >= 0) {                                                      // wave-uniform
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) stage.slot[ch * kTileStride] = acc[ch];
+                stage.advance();
+            }
+        }
+    }
+    if (stage.staged) stage.now();
+}
+
 template <int VPT, int C>
 __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
@@ -489,7 +538,10 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
     const int v0 = (vt * SIG_WAVE + lane) * VPT;
     const int vc = (v0 < a.voices) ? v0 : 0;
     const int64_t p0 = a.position + b_first * a.N;
-    if (!steady_wave(a, v0, VPT, p0, nb)) return;                             // the walker does this wave
+    if (!steady_wave(a, v0, VPT, p0, nb)) {                                   // wave-uniform, rare
+        steady_fallback_span<VPT, C>(a, bus, tile, lane, vt, b_first, nb, v0);
+        return;
+    }
     const double* sc = a.steady_consts;
 
     double na1[VPT], na2[VPT], nm[VPT], yss[VPT], dss[VPT], wt[C][VPT];
@@ -626,7 +678,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
     int vpt;
     pick_geometry(a, 4, vpt, a.span);
     if (KIND == SIG_OSC_SINE && (a.N >= a.ctx || a.position >= a.ctx)) {      // at most the first block has a short context
-        // closed-form waves first, then the walker for the waves that do not qualify (each kernel skips the other's)
+        // per-voice constants, then one launch: closed form per wave, or its built-in plain fallback (steady_fallback_span)
         const char* e = getenv("SIG_FUSED_STEADY");                            // tuning / test hook
         a.steady = e ? atoi(e) : 1;
         if (a.steady) {
@@ -645,8 +697,10 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
             if (e2) return e2;
         }
     }
-    int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
-    if (err) return err;
+    if (!a.steady) {                                                           // (Sine with the closed form: that launch did every wave)
+        const int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
+        if (err) return err;
+    }
     const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     return sig_bus::launch_partials<C>(bus.partials, tiles, bus.rows, out, out_ld, stream);
 }
