@@ -7,6 +7,8 @@
 // skipped relative to the per-node path are the float32 roundings of the filter and RingMod stores, so results
 // agree with it to those roundings (and are closer to the f64 reference).  Lanes are voices (1 or 4 per lane),
 // rows are walked serially with kRing row loads in flight; the bus sums go through sig_bus::Tile.
+#include <type_traits>
+
 #include "sig_adsr.h"
 #include "sig_biquad.h"
 #include "sig_bus_tile.h"
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
 
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
     double na1[VPT], na2[VPT], z0[VPT], z1[VPT], w[C][VPT];
-    sig_env::Voice ev[ENV ? VPT : 1];
+    sig_env::Segment seg[ENV ? VPT : 1];                                       // the envelope stage each voice is in
     bool ok = true, any_live = false;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
         z0[i] = 0.0; z1[i] = 0.0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) w[ch][i] = live ? (a.pan ? a.pan[ch * a.pan_ld + v] * q.b0 : q.b0) : 0.0;
-        if (ENV) ev[i] = sig_env::load_voice(env, v);
+        if (ENV) seg[i].end = -1.0;                                            // (re)derived at the first output row
     }
     if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
     const float* src = a.in + (b * a.N - c) * a.in_ld + vc;                    // first context row of this block
     sig_bus::Tile<C> bus(lds[threadIdx.x >> 6], lane, a.partials + (int64_t)vt * a.rows * C);
     constexpr int R = sig_bus::Tile<C>::R;
-    static_assert(kRing % R == 0, "a ring of rows is a whole number of bus groups");
+    constexpr int kChunk = (kRing > R) ? kRing : R;                           // rows per unrolled chunk: whole bus groups, whole rings
+    static_assert(kChunk % R == 0 && kChunk % kRing == 0, "a chunk of rows is a whole number of bus groups and of ring turns");
     double q_lane = 0.0;
 
     Vec ring[kRing];
@@ -79,14 +82,18 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
         const int r = (u < total) ? u : total - 1;
         ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)r * a.in_ld);
     }
-    for (int r0 = 0; r0 < total; r0 += kRing) {
+    // kChunk rows: CHECKED re-derives a voice's envelope stage at the row where it ends (sig_adsr.h: Segment); when no
+    // stage of the lane's voices ends inside the chunk (the usual case: a voice has five stage boundaries in its
+    // whole life) the unchecked copy runs, whose row is just  y *= l0 + slope * (t - t0)
+    auto chunk = [&](int r0, auto checked_tag) {
+        constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
-        for (int u = 0; u < kRing; ++u) {
+        for (int u = 0; u < kChunk; ++u) {
             const int r = r0 + u;                                              // rows >= total repeat the last row: never stored
             double x[VPT], y[VPT];
-            unpack(ring[u], x);
+            unpack(ring[u % kRing], x);
             const int rn = (r + kRing < total) ? r + kRing : total - 1;        // refill this slot
-            ring[u] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * a.in_ld);
+            ring[u % kRing] = *reinterpret_cast<const Vec*>(src + (int64_t)rn * a.in_ld);
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 y[i] = x[i] + z0[i];                                           // DF2T of [1, s2, 1] / [1, a1, a2]
@@ -98,7 +105,13 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
                 if (r >= c) {                                                  // wave-uniform: context rows are never stored
                     const double t = sig_readlane_f64(q_lane, r & 63);
 #pragma unroll
-                    for (int i = 0; i < VPT; ++i) y[i] *= sig_env::level(ev[i], t);
+                    for (int i = 0; i < VPT; ++i) {
+                        if (CHECKED && !(t < seg[i].end)) {                    // a stage boundary: rare, per lane
+                            const int v = (v0 + i < a.voices) ? v0 + i : vc;
+                            seg[i] = sig_env::segment_at(sig_env::load_voice(env, v), t);
+                        }
+                        y[i] *= fma(seg[i].slope, t - seg[i].t0, seg[i].l0);
+                    }
                 }
             }
             double acc[C];
@@ -115,6 +128,17 @@ __global__ __launch_bounds__(256) void biquad_bus_kernel(Args a, sig_env::AdsrRo
                     bus.flush(b * a.N + lo - c, (c > lo) ? c - lo : 0, (total - lo < R) ? total - lo : R);
             }
         }
+    };
+    for (int r0 = 0; r0 < total; r0 += kChunk) {
+        bool settled = true;
+        if (ENV) {
+            const double t_last = (double)(p_b - c + r0 + kChunk - 1) / a.rate;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) settled &= t_last < seg[i].end;
+            settled = __all(settled);
+        }
+        if (ENV && !settled) chunk(r0, std::true_type{});
+        else chunk(r0, std::false_type{});
     }
 }
 
@@ -126,9 +150,9 @@ int launch(Args a, const sig_env::AdsrRows& env, float* out, int64_t out_ld, hip
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * a.K + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    // the envelope form is f64-issue-bound (its registers go to the envelope constants), the plain one HBM-bound
-    constexpr int R = sig_bus::Tile<C>::R;
-    constexpr int kRing = ENV ? (R > 8 ? R : 8) : 16;                          // rows of loads in flight, a multiple of R
+    // rows of loads in flight per lane: 16 for the HBM-bound plain form; the envelope form (f64-issue-bound, one wave
+    // per SIMD because of its cold stage-derivation code) measured the same with 8 and with 2 voices per lane
+    constexpr int kRing = ENV ? 8 : 16;
     if (vec) biquad_bus_kernel<4, kRing, ENV, C><<<(unsigned)nwg, 256, 0, stream>>>(a, env);
     else     biquad_bus_kernel<1, 16, ENV, C><<<(unsigned)nwg, 256, 0, stream>>>(a, env);
     const int err = sig_launch_status();

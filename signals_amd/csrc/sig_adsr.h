@@ -50,6 +50,34 @@ __device__ __forceinline__ double level(const Voice& p, double t) {
     return (w < 0.0) ? held(p, t) : p.hold_off * rel;
 }
 
+// Piecewise-linear tracking for kernels that walk time forwards and only need the envelope to rounding (the fused
+// bus kernel, not the ADSR node itself): within one stage  level(t) = L0 + slope * (t - t0)  exactly up to rounding,
+// so a voice carries (t0, L0, slope, end) and re-derives them from the definition only when t reaches `end` -- at
+// most five times per voice over a whole stream.  The stage boundaries are those of the definition (gate_on,
+// + attack, + decay, gate_off, + release); a boundary computed here may sit one ulp of t away from where the
+// definition's comparisons switch, which moves the level by slope * ulp(t) < 1e-9.
+struct Segment { double t0, l0, slope, end; };
+
+__device__ __forceinline__ Segment segment_at(const Voice& p, double t) {
+    const double inf = __builtin_inf();
+    Segment s;
+    s.t0 = t;
+    s.l0 = level(p, t);
+    if (t < p.off) {
+        const double u = t - p.on, v = u - p.attack;
+        if (u < 0.0) { s.slope = 0.0; s.end = fmin(p.on, p.off); }
+        else if (v < 0.0) { s.slope = p.ia; s.end = fmin(p.on + p.attack, p.off); }
+        else if (fma(v, p.id, p.d_bias) < 1.0) { s.slope = p.sm1 * p.id; s.end = fmin(p.on + p.attack + 1.0 / p.id, p.off); }
+        else { s.slope = 0.0; s.end = p.off; }
+    } else {
+        const double w = t - p.off;
+        if (p.rel_bias - w * p.ir > 0.0) { s.slope = -(p.hold_off * p.ir); s.end = p.off + 1.0 / p.ir; }
+        else { s.slope = 0.0; s.end = inf; }
+    }
+    if (!(s.end > t)) s.end = inf;                      // NaN parameters or a boundary at t itself: never re-enter for this t
+    return s;
+}
+
 inline bool load_rows(const double* const* params, const int32_t* strides, AdsrRows& in) {
     if (!params || !strides) return false;
     for (int i = 0; i < 6; ++i) {
