@@ -169,3 +169,54 @@ def test_one_hour_stream_stays_finite_and_position_pure(params):
         assert float((cold.render(p0, N, 4).double() - want.double()).abs().max()) < 4e-9, p0
         latency = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE).render(p0, N, 4)      # scan chain + bus launch
         assert float((latency.double() - want.double()).abs().max()) < 1e-8, p0
+
+
+def test_config3_full_size_schedules_agree_and_spot_check():
+    """BASELINE config 3 at its own size (1024 voices, 1024-frame blocks): the engine's fused schedule (fused
+    saw+filter, then filter + envelope + bus in one pass) against the one-kernel-per-node schedule over a continued
+    stream, and 6 sampled voices of the enveloped cascade against the oracle"""
+    import sys, pathlib
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / 'tools'))
+    import measure_configs as mc
+    from oracle import chain_ref as R
+    from signals_amd.engine import BatchRenderer
+    Vc, Nc, Kc = 1024, 1024, 12
+    outs = {}
+    for fuse in (True, False):
+        bus, channels, n, _, _ = mc.c3(Vc)
+        assert (channels, n) == (1, Nc)
+        r = BatchRenderer(bus, 1, RATE, fuse=fuse)
+        outs[fuse] = torch.cat([r.render(0, Nc, Kc), r.render(Nc * Kc, Nc, 4)]).double()       # a second batch continues
+    assert bool(torch.isfinite(outs[True]).all()) and float(outs[True].abs().max()) > 1.0
+    assert float((outs[True] - outs[False]).abs().max()) < 2e-5          # bus of 1024 voices of O(1): ~1e-7 relative
+    # per-voice spot check: rebuild the graph's parameters exactly as measure_configs.c3 draws them
+    rng = np.random.default_rng(0)
+    hz, ph = rng.uniform(55, 1760, (1, Vc)), rng.uniform(0, 1, (1, Vc))
+    c1, c2 = rng.uniform(200, 8000, (1, Vc)), rng.uniform(200, 8000, (1, Vc))
+    env = {k: rng.uniform(lo, hi, (1, Vc)) for k, (lo, hi) in dict(attack=(0.001, 0.05), decay=(0.01, 0.2), sustain=(0.2, 0.9),
+                                                                  release=(0.05, 0.5), gate_on=(0.0, 0.5), gate_off=(1.0, 4.0)).items()}
+    voices = np.array([0, 1, 511, 512, 1022, 1023])
+    sub = lambda a: a[:, voices]
+    f2 = R.Filter('lp', R.Filter('lp', R.Osc('Sawtooth', R.Fixed(sub(hz)), R.Fixed(sub(ph))), R.Fixed(sub(c1))), R.Fixed(sub(c2)))
+    ref = R.render_stream(R.Binary('RingMod', f2, R.Adsr(**{k: sub(v) for k, v in env.items()})), 0, Nc, 3, len(voices))
+    bus, *_ = mc.c3(Vc)
+    rm = bus.input.sig
+    got = BatchRenderer(rm, Vc, RATE).render(0, Nc, 3)[:, torch.from_numpy(voices).cuda()].cpu().numpy()
+    assert maxerr(got, f32(ref)) < 1e-6
+
+
+def test_config5_full_size_fused_equals_two_launches():
+    """BASELINE config 5 at its own size (4096 voices, 256-frame blocks, 64 blocks): chain + mix matrix in one launch
+    is bit-identical to the per-node schedule's chain followed by sig_mix_matrix when both see the same float32 rows;
+    against the per-node engine schedule (whose chain rounds through float32 earlier) to rounding"""
+    import sys, pathlib
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / 'tools'))
+    import measure_configs as mc
+    from signals_amd.engine import BatchRenderer
+    outs = {}
+    for fuse in (True, False):
+        mm, channels, n, k, _ = mc.c5(4096)
+        outs[fuse] = BatchRenderer(mm, channels, RATE, fuse=fuse).render(0, n, k)
+    assert outs[True].shape == (256 * 64, 4096) and bool(torch.isfinite(outs[True]).all())
+    assert float((outs[True].double() - outs[False].double()).abs().max()) < 2e-6
+    assert float(outs[True].abs().max()) > 0.5
