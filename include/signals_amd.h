@@ -204,7 +204,8 @@ int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const
 int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
 
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
- * -- the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going
+ * -- Osc._eval (chain/osc.py:26-62), CritFilter._filter (chain/fx.py:85-121), Gain._eval (chain/fx.py:49-52) and the
+ * build-defined MixMatrix, i.e. the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going
  * through HBM: every 32 rows of a 64-voice group are staged as float32 in LDS and multiplied on the matrix cores
  * (exact-f32 MFMA, same k order as sig_mix_matrix, so the result equals sig_mix_matrix over sig_fused_osc_biquad's
  * output bit for bit).  voices % 64 == 0; matrix (64, 64) float32 row-major on the device. */
