@@ -222,6 +222,21 @@ int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t 
  * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second
  * kernel adds the tiles in a fixed order and rounds to f32.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
+/* Latency mode of the same graph for a Sine oscillator: ONE block per launch, rows x voices parallelism (closed form
+ * seeded per 16-row chunk), the voice tiles added and the float32 bus written by the last workgroup to finish -- a
+ * single launch per block.  `workspace`: device, sig_latency_voice_bus_workspace(voices, block_frames, bus_channels)
+ * bytes, whose last 8 bytes (the arrival counter) must be zero before the FIRST launch; the kernel re-arms it.
+ * position_dev != NULL: the block's position is read from device memory and advanced by block_frames by the same
+ * launch (hipGraph replay with no other node); otherwise `position` is used. */
+int64_t sig_latency_voice_bus_workspace(int32_t voices, int32_t block_frames, int32_t bus_channels);
+int sig_latency_voice_bus(int filt_type, int32_t rate, int64_t position, int64_t* position_dev,
+                          int32_t block_frames, int32_t context, int32_t voices,
+                          const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                          const double* cutoff, int32_t cutoff_stride,
+                          const double* gain, int32_t gain_stride,
+                          const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                          double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* Introspection: the launch geometry the two fused entry points use for this problem size -- voices per lane
  * (1, 2 or 4) and consecutive blocks per lane (the span walker, fused_voice.hip).  For measurement tools (the
  * f64 operation count per voice-sample depends on the span) and tests; no device work. */

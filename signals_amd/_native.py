@@ -25,7 +25,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
-           'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix')
+           'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
+           'sig_latency_voice_bus_workspace')
 
 
 class NativeError(RuntimeError):
@@ -100,6 +101,11 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_osc_biquad_mix.restype = ctypes.c_int
         L.sig_fused_osc_biquad_mix.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                dp, i32, dp, i32, dp, i32, dp, i32, vp, vp, i64, vp, vp]
+        L.sig_latency_voice_bus_workspace.restype = ctypes.c_int64
+        L.sig_latency_voice_bus_workspace.argtypes = [i32, i32, i32]
+        L.sig_latency_voice_bus.restype = ctypes.c_int
+        L.sig_latency_voice_bus.argtypes = [ctypes.c_int, i32, i64, vp, i32, i32, i32, dp, i32, dp, i32, dp, i32, dp, i32,
+                                            dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_geometry.restype = ctypes.c_int
         L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
         if L.sig_abi_version() != 3:
@@ -385,6 +391,50 @@ def biquad_coldstart_bus(btype: str, rate: int, position: int, block_frames: int
                                           workspace.data_ptr(), out.data_ptr(), out.stride(0),
                                           status.data_ptr() if status is not None else None, _stream(out)),
            'sig_biquad_coldstart_bus')
+    return out
+
+
+def latency_voice_bus_workspace(voices: int, block_frames: int, bus_channels: int, device) -> torch.Tensor:
+    """zeroed scratch of `latency_voice_bus` (per-tile partials + the arrival counter, which must start at zero)"""
+    return torch.zeros(lib().sig_latency_voice_bus_workspace(voices, block_frames, bus_channels) // 8, dtype=torch.float64,
+                       device=device)
+
+
+def latency_voice_bus(btype: str, rate: int, position, block_frames: int, context: int, voices: int,
+                      hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
+                      bus_gains: torch.Tensor | None, out: torch.Tensor, workspace: torch.Tensor,
+                      status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (block_frames, C) f32 <- one block of sum over voices of pan * [gain *] Filter(Sine), in one launch.
+    `position`: an int, or a one-element int64 device tensor that the launch reads AND advances by block_frames."""
+    _gpu(hertz, phase, cutoff, gain, bus_gains, out, workspace, status)
+    _audio(out, 'latency bus out')
+    rows, bus = out.shape
+    if out.dtype != torch.float32 or rows != block_frames:
+        raise NativeError(f'latency bus out must be float32 ({block_frames}, C), got {tuple(out.shape)} {out.dtype}')
+    need = lib().sig_latency_voice_bus_workspace(voices, block_frames, bus)
+    if workspace.dtype != torch.float64 or workspace.numel() * 8 < need:
+        raise NativeError(f'latency workspace needs {need} bytes of float64 (latency_voice_bus_workspace)')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    gp, gld = None, 0
+    if bus_gains is not None:
+        if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus, voices) or bus_gains.stride(1) != 1:
+            raise NativeError(f'bus gains must be float64 ({bus},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+        gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+    elif bus != 1:
+        raise NativeError('a bus without gains is mono')
+    pos_int, pos_dev = position, None
+    if isinstance(position, torch.Tensor):
+        if position.dtype != torch.int64 or position.numel() != 1 or not position.is_cuda:
+            raise NativeError('device position must be a one-element int64 GPU tensor')
+        pos_int, pos_dev = 0, position.data_ptr()
+    _check(lib().sig_latency_voice_bus(FILT_TYPES[btype], rate, pos_int, pos_dev, block_frames, context, voices, *ptrs,
+                                       gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
+                                       status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_latency_voice_bus')
     return out
 
 

@@ -30,7 +30,9 @@ struct Tile {
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) tile[(k * C + ch) * kTileStride + lane] = acc[ch];
     }
-    // tile row k holds output row out_row0 + k; rows k_lo <= k < k_hi are stored
+    // tile row k holds output row out_row0 + k; rows k_lo <= k < k_hi are stored.  AGENT: write-through (sc1) stores,
+    // for partials that another workgroup of the SAME launch reads after an arrival counter (no L2 write-back fence)
+    template <bool AGENT = false>
     __device__ __forceinline__ void flush(int64_t out_row0, int k_lo, int k_hi) {
         double s = 0.0;
 #pragma unroll
@@ -38,7 +40,10 @@ struct Tile {
         s += sig_shfl_xor_f64(s, 16);
         s += sig_shfl_xor_f64(s, 32);
         const int k = lane / C;
-        if (lane < kPairs && k >= k_lo && k < k_hi) dstp[(out_row0 + k) * C + lane % C] = s;
+        if (lane < kPairs && k >= k_lo && k < k_hi) {
+            if (AGENT) __hip_atomic_store(dstp + (out_row0 + k) * C + lane % C, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dstp[(out_row0 + k) * C + lane % C] = s;
+        }
     }
 };
 

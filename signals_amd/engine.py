@@ -92,7 +92,9 @@ class _CapturedLaunches:
     advances, so consecutive blocks replay with no host work beyond one graph launch.  The output buffer is
     owned by the graph and overwritten by every replay."""
 
-    def __init__(self, record: typing.Callable[[torch.Tensor], torch.Tensor], advance: int, position: int, keys: tuple):
+    def __init__(self, record: typing.Callable[[torch.Tensor], torch.Tensor], advance: int, position: int, keys: tuple,
+                 self_advancing: bool = False):
+        """`self_advancing`: the recorded launches move the device position themselves (sig_latency_voice_bus)"""
         dev = runtime.device()
         self.keys = keys                                    # identities of the tensors baked into the graph
         self.advance = advance
@@ -106,7 +108,8 @@ class _CapturedLaunches:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = record(self.pos)
-            _native.advance_position(self.pos, advance)
+            if not self_advancing:
+                _native.advance_position(self.pos, advance)
         self.pos.fill_(position)
         self.next_position = position
 
@@ -144,6 +147,8 @@ class BatchRenderer:
         self._stream_end: int | None = None
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
+        self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
+        self.latency_kernel = True                         # one-launch blocks for Sine chains in the latency regime
         self._replay = None                                # (graph version, N, K, launch(position)) of a one-launch plan
         self.scan_max_chains = SCAN_MAX_CHAINS             # latency regime threshold (tests set 0 to force the serial kernels)
 
@@ -807,8 +812,17 @@ class _VoiceChain:
         # time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
         small = v * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS
         chain_name, bus_name = f'fused_osc_biquad[{self.tag}]', f'fused_voice_bus[{self.tag}]'
+        # one block of a Sine chain: a single launch does chain, bus and (under hipGraph replay) the position advance
+        one_launch = small and K == 1 and self.kind == 'Sine' and o.latency_kernel
+        if one_launch and (o._latency_ws is None or o._latency_ws[0] != (v, N, bus_c)):
+            o._latency_ws = ((v, N, bus_c), _native.latency_voice_bus_workspace(v, N, bus_c, dev))
 
         def run(position, ctl, pan_now, out):
+            if one_launch:
+                return o._launch(f'latency_voice_bus[{self.tag}]',
+                                 lambda: _native.latency_voice_bus(self.btype, rate, position, N, CONTEXT, v, ctl[0], ctl[1],
+                                                                   ctl[2], ctl[3], pan_now, out, o._latency_ws[1],
+                                                                   status=status), units=rows * v)
             if small:
                 voices_buf = torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev)
                 o._launch(chain_name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
@@ -826,13 +840,16 @@ class _VoiceChain:
             cap = o._captured
             if cap is None or cap.keys != keys:
                 def record(pos_t: torch.Tensor) -> torch.Tensor:
-                    vbuf = torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev)
                     bus_out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
+                    if one_launch:
+                        return _native.latency_voice_bus(self.btype, rate, pos_t, N, CONTEXT, v, ctl[0], ctl[1], ctl[2], ctl[3],
+                                                         pan_now, bus_out, o._latency_ws[1], status=status)
+                    vbuf = torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev)
                     _native.fused_osc_biquad(self.kind, self.btype, rate, pos_t, N, K, CONTEXT,
                                              ctl[0], ctl[1], ctl[2], ctl[3], vbuf, status=status)
                     return _native.sum_bus(vbuf, pan_now, bus_out)
                 try:
-                    cap = o._captured = _CapturedLaunches(record, N * K, position, keys)
+                    cap = o._captured = _CapturedLaunches(record, N * K, position, keys, self_advancing=one_launch)
                 except RuntimeError:
                     # capture refused (another capture in progress, a profiler that forbids it ...):
                     # keep rendering with plain launches

@@ -378,12 +378,12 @@ def test_one_launch_replay_tracks_parameter_edits(golden):
     assert r._replay is not None
     a1 = r.render(256, 256, 1).cpu().numpy()                        # replayed
     ref = batched(c2_graph(g, bus=True), 0, 256, 2, 1, fuse=True)
-    assert np.array_equal(np.concatenate([a0, a1]), ref)
+    assert maxerr(np.concatenate([a0, a1]), ref) < 2e-8                # one block per launch: sig_latency_voice_bus, float32 ulps of 0.1
     src.hertz.sig.get_state().value[0, :] *= 2.0                    # in-place edit of the shared array
     b = r.render(512, 256, 1).cpu().numpy()
     g2 = {k: g[k] for k in ('c2/hertz', 'c2/phase', 'c2/cutoff', 'c2/gain')}
     g2['c2/hertz'] = g['c2/hertz'] * 2.0
-    assert np.array_equal(b, batched(c2_graph(g2, bus=True), 512, 256, 1, 1, fuse=True))
+    assert maxerr(b, batched(c2_graph(g2, bus=True), 512, 256, 1, 1, fuse=True)) < 2e-8
     gn.get_state().enabled = False                                  # pattern broken -> re-plan -> zeros (1,1) into the bus
     with pytest.raises(Exception):
         r.render(768, 256, 1)                                       # SumBus over a one-row input is rejected, like eager would mis-shape

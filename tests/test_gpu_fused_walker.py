@@ -296,3 +296,62 @@ def test_closed_form_vs_walker_over_random_parameter_draws():
             ref = oracle_chain('Sine', btype, p, pos, N, K)
             want = ref @ p['pan'][:C].T if C > 1 else ref.sum(axis=1, keepdims=True)
             assert maxerr(steady, f32(want)) < 1e-6 * scale, (draw, V, N, K, pos, btype, C)
+
+
+def run_latency(btype, p, pos, N, C=2, device_pos=False, ws=None):
+    from signals_amd import _native
+    V = p['hertz'].shape[1]
+    out = torch.full((N, C), float('nan'), device='cuda')
+    ws = ws if ws is not None else _native.latency_voice_bus_workspace(V, N, C, 'cuda')
+    position = torch.tensor([pos], dtype=torch.int64, device='cuda') if device_pos else pos
+    _native.latency_voice_bus(btype, RATE, position, N, CTX, V, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
+                              dev(p['gain']), dev(p['pan'][:C]) if C > 1 else None, out, ws)
+    if device_pos:
+        assert int(position.item()) == pos + N                    # the launch advanced the device-side position
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize('btype', ['lp', 'hp'])
+def test_one_launch_latency_kernel_matches_the_oracle(btype):
+    """sig_latency_voice_bus: one block per launch, 16-row chunks seeded in closed form, tiles added by the last
+    workgroup; ragged voice counts and block lengths, short first contexts, one hour in, every bus width, voices
+    the closed form does not cover (walked the plain way by their lane), the position read from and advanced in
+    device memory, the same workspace reused launch after launch"""
+    from signals_amd import _native
+    for V, N, pos, C in [(200, 256, 0, 2), (200, 256, 37, 2), (64, 100, 5000, 1), (1024, 256, 172_800_000, 2), (130, 250, 100, 4),
+                         (320, 17, 3, 2), (96, 1024, 48000, 1)]:
+        p = params(V, 70 + V + N)
+        if C == 4:
+            p['pan'] = np.random.default_rng(71).uniform(-1, 1, (4, V))
+        if V >= 200:
+            p['hertz'][0, 3], p['hertz'][0, 70], p['hertz'][0, 140] = 2.0, 20000.0, 0.0       # not covered by the closed form
+        ref = oracle_chain('Sine', btype, p, pos, N, 1)
+        want = f32(ref @ p['pan'][:C].T) if C > 1 else f32(ref.sum(axis=1, keepdims=True))
+        ws = _native.latency_voice_bus_workspace(V, N, C, 'cuda')
+        for device_pos in (False, True, False):                       # three launches on one workspace: the counter re-arms
+            got = run_latency(btype, p, pos, N, C=C, device_pos=device_pos, ws=ws)
+            assert np.isfinite(got).all()
+            assert maxerr(got, want) < 2e-6 * max(1.0, float(np.abs(want).max())), (V, N, pos, C, device_pos)
+
+
+def test_engine_latency_mode_uses_one_launch_and_follows_a_stream():
+    """BatchRenderer with one block per render on a Sine chain: sig_latency_voice_bus (plain and under hipGraph replay,
+    seeks included) against the batched engine"""
+    import bench
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N = 1024, 256
+    prm = bench.synth_params(V)
+    want = BatchRenderer(bench.build_graph(prm, 0, V), 2, RATE).render(0, N, 12).cpu().numpy()
+    timer = KernelTimer()
+    plain = BatchRenderer(bench.build_graph(prm, 0, V), 2, RATE, timer=timer)
+    got = np.concatenate([plain.render(i * N, N, 1).cpu().numpy() for i in range(12)])
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'latency_voice_bus[Sine,lp,gain]'}, set(timer.summary())
+    assert maxerr(got, want) < 4e-9
+    replay = BatchRenderer(bench.build_graph(prm, 0, V), 2, RATE, graph_replay=True)
+    got = np.concatenate([replay.render(i * N, N, 1).cpu().numpy().copy() for i in range(12)])
+    assert maxerr(got, want) < 4e-9
+    assert maxerr(replay.render(5 * N, N, 1).cpu().numpy(), want[5 * N:6 * N]) < 4e-9          # seek back
+    old = BatchRenderer(bench.build_graph(prm, 0, V), 2, RATE)
+    old.latency_kernel = False                                          # the scan kernel + sum_bus path stays available
+    assert maxerr(np.concatenate([old.render(i * N, N, 1).cpu().numpy() for i in range(3)]), want[:3 * N]) < 4e-9
