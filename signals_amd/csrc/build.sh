@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-u
 OBJS=()
 for f in *.hip; do
   o="${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ sig_common.h -nt "$o" ] || [ sig_osc.h -nt "$o" ] || [ sig_biquad.h -nt "$o" ] || [ sig_adsr.h -nt "$o" ] || [ ../../include/signals_amd.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ sig_common.h -nt "$o" ] || [ sig_osc.h -nt "$o" ] || [ sig_biquad.h -nt "$o" ] || [ sig_adsr.h -nt "$o" ] || [ sig_bus_tile.h -nt "$o" ] || [ ../../include/signals_amd.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
   fi
   OBJS+=("$o")
