@@ -225,7 +225,8 @@ int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_
 /* Latency mode of the same graph for a Sine oscillator: ONE block per launch, rows x voices parallelism (closed form
  * seeded per 16-row chunk), the voice tiles added and the float32 bus written by the last workgroup to finish -- a
  * single launch per block.  `workspace`: device, sig_latency_voice_bus_workspace(voices, block_frames, bus_channels)
- * bytes, whose last 8 bytes (the arrival counter) must be zero before the FIRST launch; the kernel re-arms it.
+ * bytes, whose last 8 bytes (the arrival counter) must be zero before the FIRST launch; the kernel re-arms it, so
+ * launches that share a workspace must be ordered (one stream, or events between streams).
  * position_dev != NULL: the block's position is read from device memory and advanced by block_frames by the same
  * launch (hipGraph replay with no other node); otherwise `position` is used. */
 int64_t sig_latency_voice_bus_workspace(int32_t voices, int32_t block_frames, int32_t bus_channels);
