@@ -62,7 +62,10 @@ def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2, 
     vpt, span = _native.fused_geometry(voices, N, K, ctx)
     sink = bus_channels + bus_channels / vpt if name == 'fused_voice_bus' else 2.0
     if steady and name == 'fused_voice_bus':
-        return 5.0 + sink, vpt, span
+        # launch_voice_bus: the closed-form kernel takes 8 voices per lane when that still leaves a wave per SIMD
+        if vpt == 4 and -(-voices // 512) * -(-K // span) >= 1024:
+            vpt = 8
+        return 5.0 + bus_channels + bus_channels / vpt, vpt, span
     return 2.0 * (span * N + ctx) / (span * N) + 4.0 * (N + ctx) / N + sink, vpt, span
 
 

@@ -685,12 +685,20 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
             double* consts = bus.partials + steady_consts_offset(a.voices, bus.rows, C);
             a.steady_consts = consts;
             steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+            {
+                // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
+                // 4 (two waves) by 5 % when the launch still has a wave for every SIMD -- half the flushes per sample
+                const int env_vpt = env_int("SIG_FUSED_VPT");                  // tuning / test hook
+                const int64_t waves8 = (int64_t)((a.voices + SIG_WAVE * 8 - 1) / (SIG_WAVE * 8)) * ((a.K + a.span - 1) / a.span);
+                if (env_vpt == 8 || (env_vpt == 0 && vpt == 4 && waves8 >= kWavesWanted / 2)) vpt = 8;
+            }
             a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
             const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
             if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
             switch (vpt) {
                 case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
                 case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+                case 8: fused_steady_bus_kernel<8, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
                 default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             }
             const int e2 = sig_launch_status();

@@ -70,7 +70,7 @@ def run_bus(kind, btype, p, pos, N, K, C=2):
     return out.cpu().numpy()
 
 
-GEOMETRIES = [(1, 1), (2, 1), (4, 1), (4, 2), (2, 4), (1, 8), (4, 8), (2, 3)]
+GEOMETRIES = [(1, 1), (2, 1), (4, 1), (4, 2), (2, 4), (1, 8), (4, 8), (2, 3), (8, 2)]   # 8 per lane: closed-form kernel only
 
 
 @pytest.mark.parametrize('kind', ['Sine', 'Sawtooth', 'Square', 'Triangle'])
