@@ -276,8 +276,14 @@ def sum_bus(x: torch.Tensor, gains: torch.Tensor | None, out: torch.Tensor) -> t
         if gains.dtype != torch.float64 or gains.dim() != 2 or gains.shape != (bus, voices) or gains.stride(1) != 1:
             raise NativeError(f'gains must be float64 ({bus},{voices}), got {tuple(gains.shape)} {gains.dtype}')
         gp, gld = gains.data_ptr(), gains.stride(0)
-    _check(lib().sig_sum_bus(rows, voices, x.data_ptr(), x.stride(0), _dt(x), gp, gld, bus,
-                             out.data_ptr(), out.stride(0), _dt(out), _stream(out)), 'sig_sum_bus')
+    # the kernel is built for 1, 2 and 4 bus channels; any other width is a few calls over column groups
+    c0, esz = 0, out.element_size()
+    while c0 < bus:
+        w = 4 if bus - c0 >= 4 else (2 if bus - c0 >= 2 else 1)
+        _check(lib().sig_sum_bus(rows, voices, x.data_ptr(), x.stride(0), _dt(x),
+                                 gp + c0 * gld * 8 if gp is not None else None, gld, w,
+                                 out.data_ptr() + c0 * esz, out.stride(0), _dt(out), _stream(out)), 'sig_sum_bus')
+        c0 += w
     return out
 
 

@@ -529,6 +529,8 @@ class _Batch:
         """SumBus(Filter(x)) / SumBus(RingMod(Filter(x), ADSR)) with no other reader of the filter (and of the
         RingMod and the envelope): one pass over x, nothing per-voice stored (sig_biquad_coldstart_bus)"""
         o, top, voices = self.owner, src_port.sig, src_port.channels
+        if node.channels not in (1, 2, 4):                                     # the bus widths the tile reduction is built for
+            return None
         if top is None or not top.get_state().enabled or len(top.outputs_with_ports) != 1 or (top, voices) in self._memo:
             return None
         flt, ctl = top, None

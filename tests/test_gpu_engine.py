@@ -643,6 +643,31 @@ def test_ringmod_with_adsr_in_one_pass():
     assert maxerr(got, stream(fx_mix(*(lambda b: (b.input.sig, b.input.sig.left.sig))(c3_graph(V)[0])), 0, N, K, V)) < 1e-6
 
 
+def test_three_channel_bus_over_a_filter_takes_the_general_path():
+    """bus widths other than 1, 2, 4 are not fused: filter launch + sum_bus, same values as eager"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N, K = 16, 256, 3
+    rng = np.random.default_rng(9)
+    hz, cut = rng.uniform(55, 1760, (1, V)), rng.uniform(200, 8000, (1, V))
+
+    def build():
+        inner = fx.HighPass(); inner.input = mkosc('Square', hz); inner.cutoff = fix(cut)
+        f = fx.LowPass(); f.input = inner; f.cutoff = fix(cut[:, ::-1].copy())
+        b = ext.SumBus(); b.input = f
+        b.get_state().gains = rng.uniform(-1, 1, (3, V))
+        return b
+    rng = np.random.default_rng(10)
+    bus = build()
+    timer = KernelTimer()
+    got = BatchRenderer(bus, 3, RATE, timer=timer).render(0, N, K).cpu().numpy()
+    torch.cuda.synchronize()
+    names = set(timer.summary())
+    assert 'sum_bus' in names and not any(n.startswith('biquad_bus') for n in names), names
+    rng = np.random.default_rng(10)
+    assert maxerr(got, stream(build(), 0, N, K, 3)) < 1e-6
+
+
 def fx_mix(a, b):
     from signals_amd.chain import fx
     m = fx.RingMod(); m.left = a; m.right = b
