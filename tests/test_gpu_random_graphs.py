@@ -65,7 +65,7 @@ class Builder:
                 o.hertz = self.control(100, 900)
             self.pool.append(o)
             return o
-        kind = r.choice(['lp', 'hp', 'gain', 'mix', 'ring', 'amp', 'bp'])
+        kind = r.choice(['lp', 'hp', 'gain', 'mix', 'ring', 'amp', 'bp', 'env'])
         if kind in ('lp', 'hp'):
             n = (fx.LowPass if kind == 'lp' else fx.HighPass)()
             n.input = self.audio(depth - 1)
@@ -81,13 +81,24 @@ class Builder:
             n = fx.Amp(); n.left = self.audio(depth - 1); n.right = fix(np.round(self.row(1, 3)))
         elif kind == 'mix':
             n = fx.Mix(); n.left = self.audio(depth - 1); n.right = self.audio(depth - 1); n.mix = self.control(0.1, 0.9)
+        elif kind == 'env':
+            # an ADSR whose every stage boundary falls inside the rendered windows (frames 0..1512 at 48 kHz)
+            env = self.ext.ADSR()
+            for name, (lo, hi) in dict(attack=(0.001, 0.008), decay=(0.002, 0.008), sustain=(0.2, 0.9), release=(0.002, 0.01),
+                                       gate_on=(0.0, 0.006), gate_off=(0.012, 0.03)).items():
+                setattr(env, name, fix(self.row(lo, hi, wide=r.random() < 0.8)))
+            n = fx.RingMod()
+            if r.random() < 0.5:
+                n.left = self.audio(depth - 1); n.right = env
+            else:
+                n.left = env; n.right = self.audio(depth - 1)
         else:
             n = fx.RingMod(); n.left = self.audio(depth - 1); n.right = self.audio(depth - 1)
         self.pool.append(n)
         return n
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(48))
 def test_random_graph_eager_vs_batched(seed):
     from signals_amd.engine import BatchRenderer
     b = Builder(seed)
