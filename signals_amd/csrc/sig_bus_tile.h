@@ -2,7 +2,7 @@
 //   partial[tile][row][c] = sum over the wave's voices of weight[c][v] * y[row][v]
 // A row's sum is a cross-lane sum; doing it per row with a butterfly would cost as much as the recurrences
 // themselves, so rows are staged kPairs/C at a time in a wave-private LDS tile [pair = row*C + c][lane] (row stride
-// 65 doubles: conflict-free for the transposed read) and reduced by lane = pair: 16 LDS reads + 2 shuffles per
+// 65 doubles: conflict-free for the transposed read) and reduced by lane = pair: 16 LDS reads + 2 lane-row swaps per
 // lane per flush.  bus_partials_kernel then adds the voice tiles in a fixed order (deterministic, no atomics) and
 // rounds to f32.
 #pragma once
@@ -37,8 +37,7 @@ struct Tile {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += col[k];
-        s += sig_shfl_xor_f64(s, 16);
-        s += sig_shfl_xor_f64(s, 32);
+        s = sig_sum_rows_f64(s);
         const int k = lane / C;
         if (lane < kPairs && k >= k_lo && k < k_hi) {
             if (AGENT) __hip_atomic_store(dstp + (out_row0 + k) * C + lane % C, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -70,8 +69,7 @@ struct PipelinedTile {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += pv[k];
-        s += sig_shfl_xor_f64(s, 16);
-        s += sig_shfl_xor_f64(s, 32);
+        s = sig_sum_rows_f64(s);
         if (lane < nrows * C) dstp[row0 * C + lane] = s;
     }
     __device__ __forceinline__ void now() {                                    // flush what is staged, at once

@@ -30,6 +30,27 @@ __device__ __forceinline__ double sig_shfl_xor_f64(double x, int mask) {
     return __hiloint2double(hi, lo);
 }
 
+// Sum of a double over the wave's four 16-lane rows, delivered to every lane: what  s += shfl_xor(s, 16); s += shfl_xor(s, 32)
+// computes -- the same additions in the same order, so the same bits -- but with gfx950's v_permlane16_swap /
+// v_permlane32_swap (register-to-register, VALU latency) instead of two dependent LDS round trips (ds_bpermute).
+// v_permlaneN_swap exchanges the odd N-lane groups of its first operand with the even groups of its second: fed two
+// copies of x it returns (even groups twice, odd groups twice).
+__device__ __forceinline__ double sig_sum_rows_f64(double s) {
+    {
+        const int lo = __double2loint(s), hi = __double2hiint(s);
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        s = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);      // row pairs (0,1) and (2,3)
+    }
+    {
+        const int lo = __double2loint(s), hi = __double2hiint(s);
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        s = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);      // halves
+    }
+    return s;
+}
+
 // numpy's float mod for a positive power-of-two divisor d = 1/INV_D (npy_divmod semantics):
 //   m = fmod(t, d)  (exact);  if (m != 0 && m < 0) m += d (ROUNDED, like numpy);  if (m == 0) m = +0
 // Evaluated as  t - d * floor(t * INV_D):  d * floor(..) is exact, and for t < 0 the one rounded subtraction
