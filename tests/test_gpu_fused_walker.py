@@ -211,7 +211,7 @@ def test_closed_form_kernel_leaves_unqualified_waves_to_the_walker():
     p['hertz'][0, 70] = 20000.0                              # wave 1: walker (exact phase)
     p['hertz'][0, 130] = 0.0                                 # wave 2: walker
     ref_bus = oracle_chain('Sine', 'lp', p, 512, N, K) @ p['pan'].T
-    for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 8)]:
+    for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 8), (8, 2), (8, 1)]:
         geometry(vpt, span, steady=1)
         assert maxerr(run_bus('Sine', 'lp', p, 512, N, K), f32(ref_bus)) < 2e-6, (vpt, span)
     hour = 172_800_000
@@ -281,7 +281,7 @@ def test_closed_form_vs_walker_over_random_parameter_draws():
         pos = int(rng.choice([0, 1, 99, 100, 4096, 48000 * 600]))
         btype = str(rng.choice(['lp', 'hp']))
         C = int(rng.choice([1, 2, 4]))
-        vpt, span = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4, 8]))
+        vpt, span = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 4, 8]))
         p = dict(hertz=np.exp(rng.uniform(np.log(8.0), np.log(11900.0), (1, V))) * rng.choice([-1.0, 1.0], (1, V)),
                  phase=rng.uniform(-2, 2, (1, V)), cutoff=np.exp(rng.uniform(np.log(20.0), np.log(23000.0), (1, V))),
                  gain=rng.uniform(0.1, 1, (1, V)) / np.sqrt(V), pan=rng.uniform(-1, 1, (4, V)))
