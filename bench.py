@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8
 # per consumer (SURVEY.md §8d, C2 = 24 B over the four kernels)
 ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
               'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
-              'fused_voice_bus': 2 * 2 * 8 / 256 + 2 * 4 / 1024}   # f64 tile partials (written, re-read) + f32 stereo bus
+              'fused_voice_bus': None}    # f64 tile partials (written, re-read) + the f32 bus: depends on the voices per lane
 FUSED_KERNELS = ('fused_osc_biquad', 'fused_voice_bus')
 
 
@@ -269,8 +269,14 @@ def main():
             summ = timer.summary()
             total_ms = sum(e['ms'] for e in summ.values())
             kernels = {}
+            closed = fuse and steady_applies(params, rank * V, (rank + 1) * V, args.position,
+                                             args.position + (warmup + steps) * N * K - 1, N)
             for name, e in summ.items():
                 bpu = ALGO_BYTES.get(name.split('[')[0], 0)
+                if name.split('[')[0] == 'fused_voice_bus':
+                    vpl = fused_f64_ops_per_voice_sample('fused_voice_bus', V, N, K, steady=closed)[1]
+                    tiles = -(-V // (64 * vpl))                     # one f64 partial per (voice tile, frame, channel), written and re-read
+                    bpu = (tiles * 2 * 8 * 2 + 2 * 4) / V
                 avg_ms = e['ms'] / e['calls']
                 kernels[name] = {'calls': e['calls'], 'avg_ms': avg_ms, 'share': e['ms'] / total_ms,
                                  'algo_bytes_per_voice_sample': bpu,
@@ -289,8 +295,6 @@ def main():
                 # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
                 # the meaningful ceiling is the f64 vector issue rate,
                 # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
-                closed = fuse and steady_applies(params, rank * V, (rank + 1) * V, args.position,
-                                                 args.position + (warmup + steps) * N * K - 1, N)
                 ops, vpt, span = fused_f64_ops_per_voice_sample(dom.split('[')[0], V, N, K, steady=closed)
                 ach = ops * (summ[dom]['units'] / summ[dom]['calls']) / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
                 res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
