@@ -222,6 +222,21 @@ int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t 
  * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second
  * kernel adds the tiles in a fixed order and rounds to f32.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
+/* sig_fused_voice_bus with the per-voice constants of its Sine closed form (filter design, H(e^{j theta}), the
+ * block-start matrices: ~5 us of kernel time per call) kept by the caller across calls: `consts` is a device buffer of
+ * sig_fused_voice_consts_size(voices) bytes; consts_ready == 0 fills it (and uses it), consts_ready != 0 skips that.
+ * The buffer stays valid while hertz, cutoff, gain (their values), filt_type, rate, context, voices and
+ * min(context, position) are unchanged; the caller vouches for that.  Other waveforms ignore it. */
+int64_t sig_fused_voice_consts_size(int32_t voices);
+int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                 int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                 const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                 const double* cutoff, int32_t cutoff_stride,
+                                 const double* gain, int32_t gain_stride,
+                                 const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                 double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
+                                 double* consts, int32_t consts_ready);
+
 /* Latency mode of the same graph for a Sine oscillator: ONE block per launch, rows x voices parallelism (closed form
  * seeded per 16-row chunk), the voice tiles added and the float32 bus written by the last workgroup to finish -- a
  * single launch per block.  `workspace`: device, sig_latency_voice_bus_workspace(voices, block_frames, bus_channels)

@@ -26,7 +26,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
            'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
-           'sig_latency_voice_bus_workspace')
+           'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size')
 
 
 class NativeError(RuntimeError):
@@ -77,6 +77,11 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus.restype = ctypes.c_int
         L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                           dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_voice_consts_size.restype = ctypes.c_int64
+        L.sig_fused_voice_consts_size.argtypes = [i32]
+        L.sig_fused_voice_bus_prepared.restype = ctypes.c_int
+        L.sig_fused_voice_bus_prepared.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                                   dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp, vp, i32]
         L.sig_band_coldstart.restype = ctypes.c_int
         L.sig_band_coldstart.argtypes = [ctypes.c_int, i32, i64, i32, i32, i32, i32, dp, i32, dp, i32,
                                          vp, i64, i64, vp, i64, i32, vp, vp]
@@ -485,9 +490,12 @@ def advance_position(position: torch.Tensor, delta: int) -> None:
 def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,
                     voices: int, hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
                     gain: torch.Tensor | None, bus_gains: torch.Tensor | None, out: torch.Tensor,
-                    workspace: torch.Tensor | None = None, status: torch.Tensor | None = None) -> torch.Tensor:
-    """out (nblocks*block_frames, bus_channels) f32 <- sum over voices of pan * [gain *] Filter(Osc)"""
-    _gpu(hertz, phase, cutoff, gain, bus_gains, out, status)
+                    workspace: torch.Tensor | None = None, status: torch.Tensor | None = None,
+                    consts: torch.Tensor | None = None, consts_ready: bool = False) -> torch.Tensor:
+    """out (nblocks*block_frames, bus_channels) f32 <- sum over voices of pan * [gain *] Filter(Osc).
+    `consts`: a float64 device buffer of sig_fused_voice_consts_size(voices) bytes the caller keeps across calls for
+    the Sine closed form's per-voice constants; `consts_ready`: it already holds them for these parameters."""
+    _gpu(hertz, phase, cutoff, gain, bus_gains, out, status, consts)
     _audio(out, 'fused bus out')
     rows, bus = out.shape
     if out.dtype != torch.float32 or rows != block_frames * nblocks:
@@ -505,6 +513,15 @@ def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frame
     need = lib().sig_fused_voice_bus_workspace(voices, rows, bus)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    if consts is not None:
+        if consts.dtype != torch.float64 or consts.numel() * 8 < lib().sig_fused_voice_consts_size(voices):
+            raise NativeError('consts must be float64 of sig_fused_voice_consts_size(voices) bytes')
+        _check(lib().sig_fused_voice_bus_prepared(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks,
+                                                  context, voices, *ptrs, gp, gld, bus, workspace.data_ptr(), out.data_ptr(),
+                                                  out.stride(0), status.data_ptr() if status is not None else None,
+                                                  _stream(out), consts.data_ptr(), 1 if consts_ready else 0),
+               'sig_fused_voice_bus_prepared')
+        return out
     _check(lib().sig_fused_voice_bus(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
                                      voices, *ptrs, gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
                                      status.data_ptr() if status is not None else None, _stream(out)),

@@ -75,6 +75,8 @@ struct FusedArgs {
     int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
     int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
+    double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
+    int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
 };
 
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
@@ -682,9 +684,10 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
         const char* e = getenv("SIG_FUSED_STEADY");                            // tuning / test hook
         a.steady = e ? atoi(e) : 1;
         if (a.steady) {
-            double* consts = bus.partials + steady_consts_offset(a.voices, bus.rows, C);
+            double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
             a.steady_consts = consts;
-            steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+            if (!(a.consts_ext && a.consts_ready))
+                steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
             {
                 // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
                 // 4 (two waves) by 5 % when the launch still has a wave for every SIMD -- half the flushes per sample
@@ -981,13 +984,14 @@ extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, i
     return (steady_consts_offset(voices, rows, bus_channels) + (int64_t)kSteadyConsts * voices) * (int64_t)sizeof(double);
 }
 
-extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
-                                   int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
-                                   const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
-                                   const double* cutoff, int32_t cutoff_stride,
-                                   const double* gain, int32_t gain_stride,
-                                   const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
-                                   double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+namespace {
+int fused_voice_bus_impl(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                         const double* cutoff, int32_t cutoff_stride, const double* gain, int32_t gain_stride,
+                         const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                         double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
+                         double* consts, int32_t consts_ready)
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
@@ -998,8 +1002,44 @@ extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, in
     FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
                 hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
                 nullptr, 0, 0, status};
+    a.consts_ext = consts;
+    a.consts_ready = consts_ready;
     BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return gain ? dispatch_bus_kind<true>(osc_kind, bus_channels, a, bus, out, out_ld, s)
                 : dispatch_bus_kind<false>(osc_kind, bus_channels, a, bus, out, out_ld, s);
+}
+}  // namespace
+
+extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                   int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                   const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                   const double* cutoff, int32_t cutoff_stride,
+                                   const double* gain, int32_t gain_stride,
+                                   const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                   double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    return fused_voice_bus_impl(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride,
+                                phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
+                                bus_channels, workspace, out, out_ld, status, stream, nullptr, 0);
+}
+
+extern "C" int64_t sig_fused_voice_consts_size(int32_t voices)
+{
+    return (int64_t)kSteadyConsts * voices * (int64_t)sizeof(double);
+}
+
+extern "C" int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                            int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                            const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                            const double* cutoff, int32_t cutoff_stride,
+                                            const double* gain, int32_t gain_stride,
+                                            const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                            double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
+                                            double* consts, int32_t consts_ready)
+{
+    SIG_CHECK_ARG(consts != nullptr);
+    return fused_voice_bus_impl(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride,
+                                phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
+                                bus_channels, workspace, out, out_ld, status, stream, consts, consts_ready);
 }

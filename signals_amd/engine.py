@@ -148,6 +148,7 @@ class BatchRenderer:
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
+        self._steady_consts = None                         # (key, control tensors, buffer): closed-form constants kept across calls
         self.latency_kernel = True                         # one-launch blocks for Sine chains in the latency regime
         self._replay = None                                # (graph version, N, K, launch(position)) of a one-launch plan
         self.scan_max_chains = SCAN_MAX_CHAINS             # latency regime threshold (tests set 0 to force the serial kernels)
@@ -831,9 +832,19 @@ class _VoiceChain:
                                                                        ctl[0], ctl[1], ctl[2], ctl[3], voices_buf,
                                                                        status=status), units=rows * v)
                 return o._launch('sum_bus', lambda: _native.sum_bus(voices_buf, pan_now, out), units=rows * v)
+            # the Sine closed form's per-voice constants survive from call to call while the control tensors (held here,
+            # so their addresses cannot be recycled), the filter type and min(context, position) are the same
+            key = (tuple(id(t) for t in ctl), self.btype, rate, v, min(CONTEXT, position))
+            held = o._steady_consts
+            ready = held is not None and held[0] == key
+            if not ready:
+                size = _native.lib().sig_fused_voice_consts_size(v) // 8
+                buf = held[2] if held is not None and held[2].numel() >= size else torch.empty(size, dtype=CTRL_DTYPE, device=dev)
+                o._steady_consts = held = (key, tuple(ctl), buf)
             return o._launch(bus_name, lambda: _native.fused_voice_bus(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
                                                                        ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
-                                                                       workspace=o._workspace, status=status),
+                                                                       workspace=o._workspace, status=status,
+                                                                       consts=held[2], consts_ready=ready),
                              units=rows * v)
 
         def captured(position, ctl, pan_now):

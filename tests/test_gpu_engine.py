@@ -643,6 +643,40 @@ def test_ringmod_with_adsr_in_one_pass():
     assert maxerr(got, stream(fx_mix(*(lambda b: (b.input.sig, b.input.sig.left.sig))(c3_graph(V)[0])), 0, N, K, V)) < 1e-6
 
 
+def test_closed_form_constants_are_kept_across_batches_and_follow_parameter_edits(golden):
+    """the engine keeps the per-voice constants of sig_fused_voice_bus's closed form from batch to batch
+    (sig_fused_voice_bus_prepared) and re-derives them when a parameter array is edited in place, when the stream
+    leaves the short-context start, and when a node is swapped"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer
+    g = golden('c2')
+    N, K = 256, 8
+
+    def build(scale_hz=1.0, scale_cut=1.0):
+        f = fx.LowPass(); f.input = mkosc('Sine', g['c2/hertz'] * scale_hz, g['c2/phase']); f.cutoff = fix(g['c2/cutoff'] * scale_cut)
+        gn = fx.Gain(); gn.left = f; gn.right = fix(g['c2/gain'])
+        bus = ext.SumBus(); bus.input = gn
+        return bus, f
+    bus, f = build()
+    def renderer(node):
+        br = BatchRenderer(node, 1, RATE)
+        br.scan_max_chains = 0                       # few voices here: force the batch kernels rather than the latency path
+        return br
+    r = renderer(bus)
+    fresh = lambda pos, **kw: renderer(build(**kw)[0]).render(pos, N, K).cpu().numpy()
+    assert maxerr(r.render(0, N, K).cpu().numpy(), fresh(0)) == 0.0                 # first block has no context: T0 != T
+    assert maxerr(r.render(N * K, N, K).cpu().numpy(), fresh(N * K)) == 0.0         # constants re-derived (c0 changed) ...
+    assert r._steady_consts is not None
+    key = r._steady_consts[0]
+    assert maxerr(r.render(2 * N * K, N, K).cpu().numpy(), fresh(2 * N * K)) == 0.0 # ... then reused
+    assert r._steady_consts[0] == key
+    f.cutoff.sig.get_state().value[0, :] *= 0.5                                      # in-place edit of the cutoff array
+    assert maxerr(r.render(3 * N * K, N, K).cpu().numpy(), fresh(3 * N * K, scale_cut=0.5)) == 0.0
+    assert r._steady_consts[0] != key
+    f.input.sig.hertz = fix(g['c2/hertz'] * 2.0)                                     # another Fixed plugged in
+    assert maxerr(r.render(4 * N * K, N, K).cpu().numpy(), fresh(4 * N * K, scale_hz=2.0, scale_cut=0.5)) == 0.0
+
+
 def test_three_channel_bus_over_a_filter_takes_the_general_path():
     """bus widths other than 1, 2, 4 are not fused: filter launch + sum_bus, same values as eager"""
     from signals_amd.chain import ext, fx
