@@ -303,10 +303,10 @@ def main():
                                                'path': 'closed form: steady-state sinusoid + homogeneous transient per '
                                                        'block, no warm-up rows (fused_steady_bus_kernel)' if closed
                                                        else 'span walker (fused_walk_kernel)'}
-                res['roofline']['launches'] = ('avg_launch_ms brackets everything sig_fused_voice_bus enqueues: per-voice '
-                                               'constants (steady_prep_kernel), the chain kernel and the tile sum '
-                                               "(sig_bus::partials_kernel); the chain kernel's own duration is in "
-                                               'profiles/*_kernel_stats.csv')
+                res['roofline']['launches'] = ('avg_launch_ms brackets everything sig_fused_voice_bus enqueues: the chain '
+                                               'kernel and the tile sum (sig_bus::partials_kernel), plus steady_prep_kernel '
+                                               "on the calls where the per-voice constants change; the chain kernel's own "
+                                               'duration is in profiles/*_kernel_stats.csv')
                 res['roofline']['note'] = ('this kernel is f64-VALU-bound, not HBM-bound: see valu_f64; the HBM-bound '
                                            'node-materialised schedule is reported under alt_schedule')
             res['kernels'] = kernels
