@@ -217,10 +217,12 @@ int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t 
                              const float* matrix, float* out, int64_t out_ld, int32_t* status, void* stream);
 
 /* Fused voice chain + sum bus:  out[n,c] = sum_v bus_gains[c,v] * ([gain[v] *] Filter(Osc)[n,v])
- * (bus_gains == NULL: bus_channels == 1, plain sum).  Nothing per-voice touches HBM.  Two launches inside:
- * the chain kernel writes per-voice-tile f64 partials into `workspace` (device, at least
- * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second
- * kernel adds the tiles in a fixed order and rounds to f32.  Deterministic; no atomics. */
+ * (bus_gains == NULL: bus_channels == 1, plain sum).  Nothing per-voice touches HBM.  Launches inside: the chain
+ * kernel writes per-voice-tile f64 partials into `workspace` (device, at least
+ * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes, rows = block_frames*nblocks), a second kernel adds
+ * the tiles in a fixed order and rounds to f32; for a Sine oscillator a one-thread-per-voice kernel first derives the
+ * constants of the closed form (steady-state sinusoid + homogeneous transient per cold-started block; voices it does
+ * not cover are walked row by row in the same launch) into the tail of the workspace.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
 /* sig_fused_voice_bus with the per-voice constants of its Sine closed form (filter design, H(e^{j theta}), the
  * block-start matrices: ~5 us of kernel time per call) kept by the caller across calls: `consts` is a device buffer of
