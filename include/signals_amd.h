@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 3
+#define SIG_ABI_VERSION 4
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -260,6 +260,17 @@ int sig_latency_voice_bus(int filt_type, int32_t rate, int64_t position, int64_t
  * f64 operation count per voice-sample depends on the span) and tests; no device work. */
 int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context,
                        int32_t* voices_per_lane, int32_t* blocks_per_lane);
+/* Introspection, no device work: what sig_fused_voice_bus launches for this problem -- voices per lane (1, 2, 4 or 8),
+ * consecutive blocks per lane, and closed_form = 1 when the Sine closed-form kernel (fused_steady_bus_kernel) takes
+ * the launch, 0 for the row-by-row span walker (fused_walk_kernel).  bench.py and the tests name the kernel they
+ * time / check with it. */
+int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t voices, int32_t block_frames, int32_t nblocks,
+                             int32_t context, int32_t* voices_per_lane, int32_t* blocks_per_lane, int32_t* closed_form);
+/* Tuning / test hook of the fused entry points: force the voices per lane (0 = heuristic), the blocks per lane
+ * (0 = heuristic), the Sine closed form (-1 = heuristic, 0 = off, 1 = on) and the latency-mode prefix-scan kernel
+ * (-1 = heuristic, 0 = off, 1 = on).  Process-wide, not thread-safe against concurrent launches; the initial values
+ * come from SIG_FUSED_VPT / _SPAN / _STEADY / _SCAN, read once. */
+int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan);
 int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t position,
                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,

@@ -38,11 +38,17 @@ class SignalFlags(enum.Flag):
     SIDE_EFFECT = VIS | RECORDER | PASSTHRU
 
 
-def install_as_signals() -> None:
-    """Make `import signals.chain.osc` (and friends) resolve to this package."""
+def install_as_signals(host_plugins: bool = True) -> None:
+    """Make `import signals.chain.osc` (and friends) resolve to this package.  A script that calls this declares
+    itself written against the reference's API, so with `host_plugins` (default) node classes defined outside this
+    package are handed float64 numpy arrays at their ports, as the reference would (chain/__init__.py:245-247);
+    their numpy replies are accepted at every port regardless."""
     import importlib
     names = ['', '.discovery', '.chain', '.chain.osc', '.chain.fx', '.chain.fixed', '.chain.noise',
-             '.chain.shape', '.chain.ext', '.chain.files', '.chain.driver', '.chain.sigs']
+             '.chain.shape', '.chain.ext', '.chain.files', '.chain.driver', '.chain.sigs',
+             '.chain.vis', '.chain.dev', '.chain.discovery']
     for suffix in names:
         mod = importlib.import_module(__name__ + suffix)
         sys.modules['signals' + suffix] = mod
+    from signals_amd.chain import nodes
+    nodes.host_plugins(host_plugins)

@@ -20,13 +20,15 @@ OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
 FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
+ABI_VERSION = 4
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
            'sig_fused_voice_bus', 'sig_fused_voice_bus_workspace', 'sig_band_coldstart',
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
            'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
-           'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size')
+           'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
+           'sig_fused_voice_bus_plan', 'sig_fused_set_tuning')
 
 
 class NativeError(RuntimeError):
@@ -113,7 +115,11 @@ def lib() -> ctypes.CDLL:
                                             dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_geometry.restype = ctypes.c_int
         L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
-        if L.sig_abi_version() != 3:
+        L.sig_fused_voice_bus_plan.restype = ctypes.c_int
+        L.sig_fused_voice_bus_plan.argtypes = [ctypes.c_int, i64, i32, i32, i32, i32] + [ctypes.POINTER(ctypes.c_int32)] * 3
+        L.sig_fused_set_tuning.restype = ctypes.c_int
+        L.sig_fused_set_tuning.argtypes = [i32, i32, i32, i32]
+        if L.sig_abi_version() != ABI_VERSION:
             raise NativeError('libsignals_amd.so ABI version mismatch')
         _lib = L
     return _lib
@@ -455,6 +461,21 @@ def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
            'sig_fused_geometry')
     return vpt.value, span.value
+
+
+def fused_voice_bus_plan(kind: str, position: int, voices: int, block_frames: int, nblocks: int, context: int) -> dict:
+    """what `fused_voice_bus` launches for this problem: {'voices_per_lane', 'blocks_per_lane', 'closed_form', 'kernel'}"""
+    vpt, span, closed = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _check(lib().sig_fused_voice_bus_plan(OSC_KINDS[kind], position, voices, block_frames, nblocks, context,
+                                          ctypes.byref(vpt), ctypes.byref(span), ctypes.byref(closed)),
+           'sig_fused_voice_bus_plan')
+    kernel = f'fused_steady_bus_kernel<{vpt.value}, C>' if closed.value else f'fused_walk_kernel<{kind}, {vpt.value}, gain, C>'
+    return {'voices_per_lane': vpt.value, 'blocks_per_lane': span.value, 'closed_form': bool(closed.value), 'kernel': kernel}
+
+
+def set_fused_tuning(voices_per_lane: int = 0, blocks_per_lane: int = 0, closed_form: int = -1, scan: int = -1) -> None:
+    """tuning / test hook (process-wide): force the fused kernels' launch geometry; the defaults restore the heuristics"""
+    _check(lib().sig_fused_set_tuning(voices_per_lane, blocks_per_lane, closed_form, scan), 'sig_fused_set_tuning')
 
 
 def fused_osc_biquad_mix(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int,

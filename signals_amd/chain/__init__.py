@@ -35,10 +35,12 @@ from signals_amd.chain.nodes import (  # noqa: F401
     PassThroughResult,
     Receiver,
     Signal,
+    adopt_reply,
     as_control,
     broadcast_shape,
     concatenate,
     graph_clock,
+    host_plugins,
     port,
     result_dtype,
     state,

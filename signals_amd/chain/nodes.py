@@ -11,6 +11,7 @@ import typing
 
 import attr
 import attrs.validators
+import numpy as np
 import torch
 
 import signals_amd.discovery
@@ -123,7 +124,7 @@ class Emitter(Signal, abc.ABC):
 
     def respond(self, request: Request) -> torch.Tensor:
         self._last_request = request
-        return self._get_result(request)
+        return adopt_reply(self._get_result(request))
 
     def destroy(self) -> None:
         super().destroy()
@@ -164,17 +165,19 @@ class BoundPort:
     def request(self, loc: BlockLoc) -> torch.Tensor:
         """The reply for `loc`, shape-checked; an unplugged port answers zeros((1,1))."""
         if self.sig is None:
-            return Emitter.empty_result()
+            return np.zeros(Shape.unit()) if wants_host_arrays(self.parent) else Emitter.empty_result()
         return self._do_request(self._make_request(loc))
 
     def _make_request(self, loc: BlockLoc) -> Request:
         return Request(requestor=self.parent, port=self.name, loc=loc)
 
-    def _do_request(self, request: Request) -> torch.Tensor:
-        block = self.sig.respond(request)
+    def _do_request(self, request: Request):
+        block = adopt_reply(self.sig.respond(request))      # (a plugin may override respond() itself)
         # compare as Shape: torch.Size <= Shape would be a lexicographic tuple compare
         if not (Shape.of_array(block) <= request.loc.shape):
             raise BadShape(self.sig, block.shape, request.loc.shape)
+        if wants_host_arrays(self.parent):
+            return block.to(CTRL_DTYPE).cpu().numpy()       # what the reference hands its nodes: float64 (frames, channels)
         return block
 
     def forward(self, request: Request) -> torch.Tensor:
@@ -197,6 +200,12 @@ class BoundPort:
 
 class Receiver(Signal, abc.ABC):
     BoundPort = BoundPort        # the reference nests the class; both spellings resolve
+    # Plugin interop (reference chain/__init__.py:245-247: every `_eval` takes and returns numpy arrays).  True: this
+    # node's ports hand it float64 numpy arrays (one device-to-host copy per request) instead of device tensors, so a
+    # node written for the reference (`np.tanh(self.input.forward(request))`) runs unchanged inside a GPU graph.
+    # None: decided by `host_plugins(...)` -- nodes defined outside this package get numpy once a script has called
+    # `signals_amd.install_as_signals()`, i.e. declared itself written against the reference's API.
+    HOST_ARRAYS: typing.Optional[bool] = None
 
     def __init__(self):
         super().__init__()
@@ -250,6 +259,38 @@ def port(name: PortName) -> _Port:
         self._ports[name].assign(input_)
 
     return _Port(fget=fget, fset=fset, fdel=fdel)
+
+
+_host_plugins = False
+
+
+def host_plugins(enabled: bool) -> None:
+    """nodes defined outside `signals_amd` (plugins written against the reference) receive numpy arrays at their ports"""
+    global _host_plugins
+    _host_plugins = bool(enabled)
+
+
+def wants_host_arrays(receiver) -> bool:
+    flag = getattr(receiver, 'HOST_ARRAYS', None)
+    if flag is not None:
+        return bool(flag)
+    return _host_plugins and not type(receiver).__module__.startswith('signals_amd')
+
+
+def adopt_reply(block) -> torch.Tensor:
+    """A reply as a tensor on the render device.  Built-in nodes answer device tensors (returned as they are); a node
+    written against the reference's API answers a numpy array (chain/__init__.py:245-247), which is uploaded here
+    with this package's dtype rule -- float64 for a one-row (block-rate) reply, float32 audio otherwise.  Anything
+    that is not 2-D raises TypeError at the shape check, like the reference's Shape.of_array."""
+    if isinstance(block, torch.Tensor):
+        if block.device != runtime.device():
+            block = block.to(runtime.device())
+        return block
+    host = np.asarray(block)
+    if host.ndim != 2:
+        raise TypeError(f'a reply must be a 2-D (frames, channels) array, got shape {host.shape}')
+    host = np.ascontiguousarray(host, dtype=np.float64)
+    return torch.from_numpy(host).to(device=runtime.device(), dtype=result_dtype(host.shape[0]))
 
 
 def concatenate(blocks: typing.Sequence[torch.Tensor]) -> torch.Tensor:

@@ -7,8 +7,8 @@ map/__init__.py:104-148; coordinates :54-101), enough to load its two fixture pa
     + 1a signals.chain.fixed.Fixed enabled=true value=[[440]]
     > 1a 2a.hertz                                     -> node at 2a: .hertz = node at 1a
 
-Editing, undo/redo and the GUI are out of scope.  Node classes that only exist
-for plots (`signals.chain.vis.*`) load as `Tap`, a pass-through that keeps the topology intact;
+Editing, undo/redo and the GUI are out of scope.  The plot taps
+(`signals.chain.vis.Wave/Spec`) load as their headless pass-through namesakes in `signals_amd.chain.vis`;
 `signals.chain.files.FileWriter/FileReader` resolve to the WAV taps in `signals_amd.chain.files`.
 """
 from __future__ import annotations
@@ -24,11 +24,9 @@ import numpy as np
 
 from signals_amd import SignalsError
 from signals_amd.chain import Signal
-from signals_amd.chain.ext import Tap
 from signals_amd.chain.driver import BlockDriver, load_signal
 
 _COORD = re.compile(r'(\d+)([a-z]+)')
-_TAP_MODULES = ('signals.chain.vis',)
 
 
 class PatchError(SignalsError):
@@ -75,11 +73,7 @@ class Patch:
         key = parse_coordinates(at)
         if key in self.nodes:
             raise PatchError(f'{at} is occupied')
-        if cls_name.rpartition('.')[0] in _TAP_MODULES:
-            node = Tap(cls_name, **state)
-            state = {k: v for k, v in state.items() if k == 'enabled'}
-        else:
-            node = load_signal(cls_name)()
+        node = load_signal(cls_name)()
         new_state = copy.copy(node.get_state())
         for k, v in state.items():
             if k not in node.state_attrs():

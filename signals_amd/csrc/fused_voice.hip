@@ -488,6 +488,9 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
     const double* sc = a.steady_consts;
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
     sig_bus::PipelinedTile<C> stage(tile, lane, bus.partials + (int64_t)vt * bus.rows * C, b_first * a.N);
+    for (int i = 0; i < VPT; ++i)                                              // a rejected design is NaN in the constants
+        if (v0 + i < a.voices && a.status && sc[(int64_t)SC_NA1 * a.voices + v0 + i] != sc[(int64_t)SC_NA1 * a.voices + v0 + i])
+            atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 #pragma unroll 1
     for (int bi = 0; bi < nb; ++bi) {
         const int64_t p_b = a.position + (b_first + bi) * a.N;
@@ -554,6 +557,9 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
         const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
         auto cst = [&](int k) { return sc[(int64_t)k * a.voices + v]; };
         na1[i] = cst(SC_NA1); na2[i] = cst(SC_NA2); nm[i] = cst(SC_NM);
+        // the design is checked where the constants are made (steady_prep_kernel); a caller that keeps them across
+        // calls skips that launch, so every launch that USES a rejected design (NaN coefficients) reports it again
+        if (live && na1[i] != na1[i] && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
         const double scale = cst(SC_SCALE);
 #pragma unroll
         for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0 on the bus
@@ -631,9 +637,18 @@ int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
     return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
 }
 
-int env_int(const char* name) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : 0;
+// Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
+// _STEADY, _SCAN: read ONCE, when the first launch asks) and tests set them through sig_fused_set_tuning.
+struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1; };     // 0 / -1 = the launch heuristics decide
+Tuning& tuning() {
+    static Tuning t = [] {
+        auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        Tuning u;
+        u.vpt = env("SIG_FUSED_VPT", 0); u.span = env("SIG_FUSED_SPAN", 0);
+        u.steady = env("SIG_FUSED_STEADY", -1); u.scan = env("SIG_FUSED_SCAN", -1);
+        return u;
+    }();
+    return t;
 }
 
 // Launch geometry (tools/sweep_fused.sh).  Voices per lane: 4 amortises the per-row work shared by a lane's voices
@@ -645,7 +660,7 @@ int env_int(const char* name) {
 constexpr int64_t kWavesWanted = 2048;     // two waves per SIMD
 
 void pick_geometry(const FusedArgs& a, int max_vpt, int& vpt, int& span) {
-    const int env_vpt = env_int("SIG_FUSED_VPT"), env_span = env_int("SIG_FUSED_SPAN");   // tuning / test hooks
+    const int env_vpt = tuning().vpt, env_span = tuning().span;               // tuning / test hooks
     const int max_span = (a.N >= a.ctx) ? 8 : 1;
     auto waves = [&](int v, int s) { return (int64_t)((a.voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((a.K + s - 1) / s); };
     vpt = max_vpt; span = max_span;
@@ -674,41 +689,51 @@ int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
     return sig_launch_status();
 }
 
+// What sig_fused_voice_bus launches for this problem: voices per lane, blocks per lane, and whether the Sine closed
+// form (fused_steady_bus_kernel) takes the launch.  One decision function for the launcher and for
+// sig_fused_voice_bus_plan (tests and bench.py name the kernel they time with it).
+struct BusPlan { int vpt, span, steady; };
+BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
+    BusPlan p{4, 1, 0};
+    pick_geometry(a, 4, p.vpt, p.span);
+    if (kind == SIG_OSC_SINE && (a.N >= a.ctx || a.position >= a.ctx)) {       // at most the first block has a short context
+        p.steady = tuning().steady < 0 ? 1 : tuning().steady;                  // tuning / test hook
+        if (p.steady) {
+            // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
+            // 4 (two waves) by 5 % when the launch still has a wave for every SIMD -- half the flushes per sample
+            const int env_vpt = tuning().vpt;                                  // tuning / test hook
+            const int64_t waves8 = (int64_t)((a.voices + SIG_WAVE * 8 - 1) / (SIG_WAVE * 8)) * ((a.K + p.span - 1) / p.span);
+            if (env_vpt == 8 || (env_vpt == 0 && p.vpt == 4 && waves8 >= kWavesWanted / 2)) p.vpt = 8;
+        }
+    }
+    return p;
+}
+
 template <int KIND, bool GAIN, int C>
 int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
-    int vpt;
-    pick_geometry(a, 4, vpt, a.span);
-    if (KIND == SIG_OSC_SINE && (a.N >= a.ctx || a.position >= a.ctx)) {      // at most the first block has a short context
+    const BusPlan plan = plan_voice_bus(a, KIND);
+    const int vpt = plan.vpt;
+    a.span = plan.span;
+    a.steady = plan.steady;
+    if (a.steady) {
         // per-voice constants, then one launch: closed form per wave, or its built-in plain fallback (steady_fallback_span)
-        const char* e = getenv("SIG_FUSED_STEADY");                            // tuning / test hook
-        a.steady = e ? atoi(e) : 1;
-        if (a.steady) {
-            double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
-            a.steady_consts = consts;
-            if (!(a.consts_ext && a.consts_ready))
-                steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
-            {
-                // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
-                // 4 (two waves) by 5 % when the launch still has a wave for every SIMD -- half the flushes per sample
-                const int env_vpt = env_int("SIG_FUSED_VPT");                  // tuning / test hook
-                const int64_t waves8 = (int64_t)((a.voices + SIG_WAVE * 8 - 1) / (SIG_WAVE * 8)) * ((a.K + a.span - 1) / a.span);
-                if (env_vpt == 8 || (env_vpt == 0 && vpt == 4 && waves8 >= kWavesWanted / 2)) vpt = 8;
-            }
-            a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
-            const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
-            if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-            switch (vpt) {
-                case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-                case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-                case 8: fused_steady_bus_kernel<8, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-                default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            }
-            const int e2 = sig_launch_status();
-            if (e2) return e2;
+        double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
+        a.steady_consts = consts;
+        if (!(a.consts_ext && a.consts_ready))
+            steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+        a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+        const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
+        if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        switch (vpt) {
+            case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 8: fused_steady_bus_kernel<8, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
         }
-    }
-    if (!a.steady) {                                                           // (Sine with the closed form: that launch did every wave)
+        const int e2 = sig_launch_status();
+        if (e2) return e2;
+    } else {                                                                   // (Sine with the closed form: that launch did every wave)
         const int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
         if (err) return err;
     }
@@ -837,8 +862,7 @@ template <int KIND, bool GAIN>
 int launch_fused(FusedArgs a, hipStream_t stream)
 {
     {
-        const char* scan_str = getenv("SIG_FUSED_SCAN");                      // tuning / test hook
-        const int scan_env = scan_str ? atoi(scan_str) : -1;
+        const int scan_env = tuning().scan;                                    // tuning / test hook
         const int64_t chains = (int64_t)a.voices * a.K;
         const bool fits = a.ctx + a.N <= kScanMaxL * SIG_WAVE;
         const bool want = scan_env >= 0 ? scan_env != 0 : chains <= kScanMaxChains;
@@ -976,6 +1000,29 @@ extern "C" int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t 
     pick_geometry(a, 4, vpt, span);
     *voices_per_lane = vpt;
     *blocks_per_lane = span;
+    return 0;
+}
+
+extern "C" int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t voices, int32_t block_frames, int32_t nblocks,
+                                       int32_t context, int32_t* voices_per_lane, int32_t* blocks_per_lane,
+                                       int32_t* closed_form)
+{
+    SIG_CHECK_ARG(voices >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && position >= 0);
+    SIG_CHECK_ARG(voices_per_lane && blocks_per_lane && closed_form);
+    FusedArgs a{};
+    a.position = position; a.N = block_frames; a.K = nblocks; a.ctx = context; a.voices = voices;
+    const BusPlan p = plan_voice_bus(a, osc_kind);
+    *voices_per_lane = p.vpt;
+    *blocks_per_lane = p.span;
+    *closed_form = p.steady;
+    return 0;
+}
+
+extern "C" int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan)
+{
+    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0 && closed_form >= -1 && scan >= -1);
+    Tuning& t = tuning();
+    t.vpt = voices_per_lane; t.span = blocks_per_lane; t.steady = closed_form; t.scan = scan;
     return 0;
 }
 

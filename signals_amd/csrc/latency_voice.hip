@@ -16,6 +16,13 @@
 #include "sig_bus_tile.h"
 #include "sig_osc.h"
 
+// Memory order of the arrival ticket (agent scope).  __ATOMIC_ACQ_REL is the textbook hand-off (release of this
+// workgroup's partials, acquire of everybody else's); __ATOMIC_RELAXED relies on the write-through / sc1-load form that
+// MI355X_MICROARCH.md lists under "valid forms" for inter-workgroup hand-offs.  tools/time_latency.py measures both.
+#ifndef SIG_LATENCY_TICKET_ORDER
+#define SIG_LATENCY_TICKET_ORDER __ATOMIC_ACQ_REL
+#endif
+
 namespace {
 
 using sig_biquad::Biquad;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256) void latency_voice_bus_kernel(Args a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0)
-        last_flag = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+        last_flag = (__hip_atomic_fetch_add(a.ticket, 1u, SIG_LATENCY_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (!last_flag) return;
     const int n = a.N * C;

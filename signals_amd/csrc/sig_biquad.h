@@ -14,7 +14,7 @@ struct Biquad { double b0, b1, b2, a1, a2; };
 __device__ __forceinline__ bool design_butter2(int type, double cutoff, double rate, Biquad& q) {
     double wn = cutoff / (rate * 0.5);                      // scaled_crit /= rate / 2
     wn = (wn < 0.0) ? 0.0 : ((wn > 1.0) ? 1.0 : wn);        // clip(0, 1); NaN stays NaN
-    const bool bad = (wn <= 0.0) || (wn >= 1.0);
+    const bool bad = !(wn > 0.0 && wn < 1.0);               // scipy: `if not (all(Wn > 0) and all(Wn < 1)): raise` -- NaN raises too
     const double k = tan(kPi * wn / 2.0);
     const double k2 = k * k;
     const double nrm = 1.0 / (1.0 + kSqrt2 * k + k2);
@@ -56,7 +56,7 @@ __device__ __forceinline__ Cx cx_sqrt(Cx z) {
 __device__ __forceinline__ bool design_band2(int type, double lo_hz, double hi_hz, double rate, Biquad& first, Biquad& last) {
     auto scaled = [&](double hz) { double w = hz / (rate * 0.5); return (w < 0.0) ? 0.0 : ((w > 1.0) ? 1.0 : w); };
     const double wl = scaled(lo_hz), wh = scaled(hi_hz);
-    const bool bad = (wl <= 0.0) || (wl >= 1.0) || (wh <= 0.0) || (wh >= 1.0) || (wl >= wh);
+    const bool bad = !(wl > 0.0 && wl < 1.0 && wh > 0.0 && wh < 1.0 && wl < wh);   // NaN fails every comparison: bad
     const double w1 = 4.0 * tan(kPi * wl / 2.0), w2 = 4.0 * tan(kPi * wh / 2.0);
     const double bw = w2 - w1, wo2 = w1 * w2;
     const Cx p = {-0.70710678118654757, 0.70710678118654757};

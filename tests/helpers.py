@@ -13,6 +13,7 @@ OSC = {'Sine': osc.Sine, 'Square': osc.Square, 'Sawtooth': osc.Sawtooth, 'Triang
 
 class Probe(Receiver):
     input = port('input')
+    HOST_ARRAYS = False           # written against signals_amd: takes device tensors
 
     @classmethod
     def flags(cls):

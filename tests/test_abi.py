@@ -32,7 +32,7 @@ def test_header_and_binding_agree():
 def test_every_declared_symbol_is_exported(lib):
     for name in declared_symbols():
         assert getattr(lib, name) is not None, name
-    assert lib.sig_abi_version() == 3
+    assert lib.sig_abi_version() == 4
 
 
 def test_argument_errors_do_not_reach_the_device(lib):
@@ -60,3 +60,18 @@ def test_fused_geometry_needs_no_device():
     assert _native.fused_geometry(1024, 64, 4096, 100)[1] == 1          # N < ctx: no spans
     vpt, span = _native.fused_geometry(1024, 256, 1, 100)                # latency mode: spread the voices
     assert vpt == 1 and span == 1
+
+
+def test_voice_bus_plan_names_the_bench_kernel():
+    """sig_fused_voice_bus_plan is pure host logic: the bench geometry runs the closed form at 8 voices x 8 blocks per lane"""
+    from signals_amd import _native
+    plan = _native.fused_voice_bus_plan('Sine', 0, 1024, 256, 4096, 100)
+    assert plan == {'voices_per_lane': 8, 'blocks_per_lane': 8, 'closed_form': True, 'kernel': 'fused_steady_bus_kernel<8, C>'}
+    assert _native.fused_voice_bus_plan('Sawtooth', 0, 1024, 256, 4096, 100)['closed_form'] is False
+    assert _native.fused_voice_bus_plan('Sine', 0, 1024, 64, 8, 100)['closed_form'] is False     # N < ctx at position 0
+    _native.set_fused_tuning(closed_form=0)
+    try:
+        assert _native.fused_voice_bus_plan('Sine', 0, 1024, 256, 4096, 100)['closed_form'] is False
+    finally:
+        _native.set_fused_tuning()
+    assert _native.fused_voice_bus_plan('Sine', 0, 1024, 256, 4096, 100)['closed_form'] is True

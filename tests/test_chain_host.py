@@ -27,6 +27,7 @@ def _cpu_device():
 
 class Probe(chain.Receiver):
     input = port('input')
+    HOST_ARRAYS = False           # written against signals_amd: takes device tensors
 
     @classmethod
     def flags(cls):
@@ -123,7 +124,7 @@ def test_qualified_names_and_flags():
     assert load_signal('signals_amd.chain.ext.SumBus') is ext.SumBus
     with pytest.raises(TypeError):
         load_signal('signals.chain.osc.Osc')        # abstract
-    signals_amd.install_as_signals()
+    signals_amd.install_as_signals(host_plugins=False)
     import signals.chain.fx
     assert signals.chain.fx.Gain is fx.Gain
 
@@ -159,6 +160,35 @@ def test_fixed_resident_copy_tracks_the_array():
     assert f.resident()[0, 0] == 440.0
     f.get_state().value = np.ones((5, 2))
     assert f.resident().dtype == torch.float32 and f.resident().shape == (5, 2)
+
+
+def test_fixed_sees_in_place_edits_of_arrays_of_every_size():
+    """the reference's Fixed._eval returns the live array (fixed.py:38-39): an in-place edit of ANY array is rendered
+    at the next reply -- also beyond the 65 536 elements an earlier version stopped watching at, through strided views,
+    and after an in-place reshape; NaNs do not force a re-upload per reply"""
+    for n in (10, 1024, 70000, 1 << 18):
+        f = fixed.Fixed()
+        v = np.zeros((1, n))
+        f.get_state().value = v
+        t = f.resident()
+        assert f.resident() is t
+        v[0, n - 3] = 3.5
+        assert f.resident() is not t and f.resident()[0, n - 3] == 3.5, n
+        assert f.resident() is f.resident()
+    base = np.zeros((4, 8))
+    f = fixed.Fixed()
+    f.get_state().value = base[:, ::2]            # a view: the edit goes through the base array
+    f.resident()
+    base[1, 2] = 7.0
+    assert f.resident()[1, 1] == 7.0
+    f = fixed.Fixed()
+    f.get_state().value = np.full((1, 4), np.nan)
+    assert f.resident() is f.resident()
+    v = np.arange(8.0).reshape(1, 8)
+    f.get_state().value = v
+    assert f.resident().shape == (1, 8)
+    v.shape = (2, 4)                               # same bytes, another layout
+    assert f.resident().shape == (2, 4)
 
 
 def test_unplugged_and_disabled_answer_unit_zero():
@@ -301,3 +331,117 @@ def test_graph_version_bumps_on_mutation():
     v1 = chain.graph_clock.version
     s.set_state(osc.Sine.State(enabled=False))
     assert chain.graph_clock.version > v1
+
+
+class NumpyRamp(chain.ExplicitChannelsEmitter):
+    """a generator written against the REFERENCE's API: `_eval` returns a float64 numpy array (chain/__init__.py:245-247)"""
+
+    @classmethod
+    def flags(cls):
+        return SignalFlags.GENERATOR
+
+    def _eval(self, request):
+        loc = request.loc
+        return loc.frame_range / loc.rate * np.arange(1, loc.shape.channels + 1).reshape(1, -1)
+
+
+class NumpySquarer(chain.ImplicitChannels):
+    """an effect written against the reference's API: numpy in, numpy out"""
+    input = port('input')
+    HOST_ARRAYS = True
+
+    @classmethod
+    def flags(cls):
+        return SignalFlags.EFFECT
+
+    def _eval(self, request):
+        x = self.input.forward(request)
+        assert isinstance(x, np.ndarray) and x.dtype == np.float64
+        return np.square(x)
+
+
+def test_numpy_plugin_nodes_interoperate_at_the_ports():
+    """replies of reference-style nodes are uploaded at the port (float64 for one row, float32 audio otherwise); a
+    receiver that asks for host arrays gets float64 numpy; ranks other than 2 raise TypeError like Shape.of_array"""
+    src = NumpyRamp(); src.get_state().channels = 3
+    p = Probe(); p.input = src
+    got = p.input.request(chain.BlockLoc(position=48000, rate=48000, shape=chain.Shape(4, 3)))
+    assert isinstance(got, torch.Tensor) and got.dtype == torch.float32 and tuple(got.shape) == (4, 3)
+    want = (np.arange(48000, 48004).reshape(-1, 1) / 48000) * np.array([[1, 2, 3]])
+    assert np.array_equal(got.numpy(), want.astype(np.float32))
+    row = p.input.request(chain.BlockLoc(position=7, rate=48000, shape=chain.Shape(1, 3)))
+    assert row.dtype == torch.float64 and np.array_equal(row.numpy(), (np.array([[7]]) / 48000) * np.array([[1, 2, 3]]))
+    sq = NumpySquarer(); sq.input = src
+    p2 = Probe(); p2.input = sq
+    got2 = p2.input.request(chain.BlockLoc(position=48000, rate=48000, shape=chain.Shape(4, 3)))
+    assert np.array_equal(got2.numpy(), np.square(want.astype(np.float32).astype(np.float64)).astype(np.float32))
+    del sq.input
+    assert np.array_equal(p2.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(4, 3))).numpy(),
+                          np.zeros((1, 1)))                      # unplugged: zeros((1, 1)) as numpy, squared, uploaded
+
+    class Flat(NumpyRamp):
+        def _eval(self, request):
+            return np.zeros(request.loc.shape.frames)              # 1-D: the reference raises TypeError (chain/__init__.py:84)
+    bad = Flat(); p.input = bad
+    with pytest.raises(TypeError):
+        p.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(4, 1)))
+
+
+def test_install_as_signals_aliases_every_chain_module_scripts_import():
+    import importlib
+    import signals_amd
+    from signals_amd.chain import nodes
+    try:
+        signals_amd.install_as_signals()
+        for name in ('signals.chain.vis', 'signals.chain.dev', 'signals.chain.discovery', 'signals.chain.files'):
+            assert importlib.import_module(name).__name__.startswith('signals_amd.chain.')
+        import signals.chain.discovery as d
+        import signals.chain.vis as vis
+        import signals.chain.dev as dev
+        assert d.load_signal('signals.chain.vis.Wave') is vis.Wave and vis.Wave.cls_name() == 'signals.chain.vis.Wave'
+        assert vis.Wave().state_attrs() == {'enabled', 'min_amp', 'max_amp'}
+        assert vis.Spec().state_attrs() == {'enabled', 'min_freq', 'max_freq', 'bands'}
+        with pytest.raises(d.BadSyntax):
+            d.load_signal('not a name')
+        with pytest.raises(d.BadPath):
+            d.load_signal('signals.chain.osc.Nope')
+        with pytest.raises(d.InvalidObject):
+            d.load_signal('signals.chain.osc.Osc')             # abstract
+        sink = dev.SinkDevice()
+        assert sink.flags() & SignalFlags.SINK_DEVICE and sink.port_names() == ['input'] and sink.tell() == 0
+        # a node class defined outside the package is a reference-style plugin once a script installed the alias
+        class Foreign(chain.Receiver):
+            input = port('input')
+            @classmethod
+            def flags(cls):
+                return SignalFlags(0)
+        assert nodes.wants_host_arrays(Foreign()) is True and nodes.wants_host_arrays(Probe()) is False
+    finally:
+        nodes.host_plugins(False)
+
+
+def test_library_scan_finds_plugin_nodes(tmp_path):
+    """chain/discovery.py:71-93: any concrete Signal subclass defined in a scanned module is a node"""
+    from signals_amd.chain import discovery
+    (tmp_path / 'my_plugin.py').write_text(
+        'import numpy as np\n'
+        'from signals_amd import SignalFlags\n'
+        'from signals_amd.chain import ExplicitChannelsEmitter\n'
+        'class Dc(ExplicitChannelsEmitter):\n'
+        '    @classmethod\n'
+        '    def flags(cls):\n'
+        '        return SignalFlags.GENERATOR\n'
+        '    def _eval(self, request):\n'
+        '        return np.ones(request.loc.shape)\n'
+        'class _Hidden(Dc):\n'
+        '    pass\n')
+    lib = discovery.Library([tmp_path / 'my_plugin.py'])
+    lib.scan()
+    assert 'my_plugin.Dc' in lib.names and not any('_Hidden' in n for n in lib.names)
+    for name in ('signals.chain.osc.Sine', 'signals.chain.fx.LowPass', 'signals.chain.fixed.Fixed', 'signals.chain.vis.Wave'):
+        assert name in lib.names
+    assert not any(n.endswith('.Osc') or 'SinkDevice' in n or 'BlockDriver' in n for n in lib.names)   # abstract / devices
+    cls = discovery.load_signal('my_plugin.Dc')
+    node = cls(); node.get_state().channels = 2
+    p = Probe(); p.input = node
+    assert np.array_equal(p.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(3, 2))).numpy(), np.ones((3, 2)))

@@ -75,6 +75,7 @@ class OracleRamp(R.Node):
 
 class Probe(Receiver):
     input = port('input')
+    HOST_ARRAYS = False
 
     @classmethod
     def flags(cls):

@@ -21,15 +21,15 @@ def _device():
     from signals_amd import runtime
     runtime.set_device('cuda:0')
     yield
-    for k in ('SIG_FUSED_VPT', 'SIG_FUSED_SPAN', 'SIG_FUSED_SCAN', 'SIG_FUSED_STEADY'):
-        os.environ.pop(k, None)
+    from signals_amd import _native
+    _native.set_fused_tuning()                               # back to the launch heuristics
 
 
 def geometry(vpt, span, steady=1):
-    os.environ['SIG_FUSED_VPT'] = str(vpt)
-    os.environ['SIG_FUSED_SPAN'] = str(span)
-    os.environ['SIG_FUSED_SCAN'] = '0'                       # the serial walker, not the latency-mode scan kernel
-    os.environ['SIG_FUSED_STEADY'] = str(steady)             # Sine + bus: closed-form kernel for the waves that qualify
+    """force the launch geometry (sig_fused_set_tuning): voices per lane, blocks per lane, the serial walker rather than
+    the latency-mode scan kernel, and whether Sine + bus uses the closed-form kernel for the waves that qualify"""
+    from signals_amd import _native
+    _native.set_fused_tuning(vpt, span, steady, 0)
 
 
 def dev(a):

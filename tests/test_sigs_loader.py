@@ -31,8 +31,9 @@ def test_vis_test_patch_topology():
     p = sigs.load(DATA / 'vis_test.sigs')
     assert isinstance(p['1c'], Fixed) and p['1c'].get_state().value.dtype == np.int64
     assert isinstance(p['2c'], osc.Sine) and p['2c'].hertz.sig is p['1c']
-    assert isinstance(p['3c'], sigs.Tap) and p['3c'].original_cls_name == 'signals.chain.vis.Wave'
-    assert p['3c'].original_state['min_amp'] == -1.0
+    from signals_amd.chain import ext, vis
+    assert type(p['3c']) is vis.Wave and isinstance(p['3c'], ext.Tap) and p['3c'].cls_name() == 'signals.chain.vis.Wave'
+    assert p['3c'].get_state().min_amp == -1.0 and p['3c'].get_state().max_amp == 1.0
     sink = p['4c']
     assert isinstance(sink, BlockDriver) and sink.input.sig is p['3c'] and list(p.sinks.values()) == [sink]
 
