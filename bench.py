@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1]): per GPU a 1024-voice
 `Fixed -> Sine -> LowPass -> Gain -> SumBus(stereo)` graph built through the node API and rendered by
-the batched engine, one step = one batch of `--blocks` (default 1024) consecutive 256-frame blocks of synthetic
+the batched engine, one step = one batch of `--blocks` (default 4096) consecutive 256-frame blocks of synthetic
 parameters (numpy default_rng(0): hertz U(55,1760), phase U(0,1), cutoff U(200,8000), gain U(0,1)/V,
 pan theta U(0,pi/2)), already resident in HBM.  With N > 1 GPUs every rank renders its own 1024 voices
 (weak scaling, no data-path traffic) and the stereo bus is summed onto rank 0 with one RCCL reduce per
@@ -12,9 +12,16 @@ batch (the path's only exchange step), overlapped with the next 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--voices V] [--frames F]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (HIP events around every launch, on the launch stream) and `cpu_baseline` (the CPU oracle,
-structured like the reference: per-channel butter + sosfilt per block, timed on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  * `roofline`: the dominant kernel of the timed steps against the ceiling that bounds it (HIP events around every
+    launch, on the launch stream) -- the f64 vector issue rate for the fused voice kernels (their HBM view nested
+    under `hbm`), HBM bandwidth for the per-node kernels;
+  * `max_abs_error`: blocks {0..7, middle, last} of the LAST TIMED batch's own output against the CPU oracle, with
+    the name of the device kernel that produced them (BASELINE.json's second metric);
+  * `sustained`: the same steps repeated for >= 2 s of wall time (clocks settled, visible to a busy sampler);
+  * `configs`: BASELINE.json's other single-GPU configurations (C3, C5), each with its own roofline and error;
+  * `cpu_baseline`: the CPU oracle, structured like the reference (per-channel butter + sosfilt per block), timed on
+    a bounded sample.
 """
 import argparse
 import json
@@ -30,14 +37,23 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-RATE = 48000
+import bench_configs as cfg
+
+RATE = cfg.RATE
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+F64_VALU_PEAK = 39.3            # T f64 instruction-lanes/s: 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz (= 78.6 TFLOP/s as FMAs)
 # algorithmic HBM bytes per voice-sample, f32 storage, every node output written once and read once
-# per consumer (SURVEY.md §8d, C2 = 24 B over the four kernels)
-ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4,
-              'fused_osc_biquad': 4,      # fused chain: only the f32 store reaches HBM
-              'fused_voice_bus': None}    # f64 tile partials (written, re-read) + the f32 bus: depends on the voices per lane
-FUSED_KERNELS = ('fused_osc_biquad', 'fused_voice_bus')
+# per consumer (C2 = 24 B over four kernels, C3 = 40 B, C5's matrix node 8 B)
+ALGO_BYTES = {'osc_bank': 4, 'biquad_coldstart': 8, 'elementwise': 8, 'sum_bus': 4, 'adsr': 4, 'adsr_apply': 8,
+              'biquad_bus': 4, 'mix_matrix': 8,
+              'fused_osc_biquad': 4,          # fused chain: only the f32 store reaches HBM
+              'fused_osc_biquad_mix': 4,      # chain + matrix in one launch: only the mixed f32 rows are stored
+              'fused_cascade_bus': None,      # cascade + envelope + bus: f64 tile partials + the bus (like fused_voice_bus)
+              'fused_voice_bus': None}        # f64 tile partials (written, re-read) + the f32 bus: depends on the voices per lane
+VALU_BOUND = ('fused_voice_bus', 'fused_cascade_bus')      # kernels whose ceiling is the f64 vector issue rate, not HBM
+
+synth_params = cfg.c2_params
+build_graph = cfg.c2_graph
 
 
 def steady_applies(p, lo, hi, first_frame, last_frame, N, ctx=100):
@@ -47,7 +63,7 @@ def steady_applies(p, lo, hi, first_frame, last_frame, N, ctx=100):
     d = hz / RATE
     dr = d - np.rint(d)
     t = np.abs(np.stack([first_frame / RATE * hz + ph, last_frame / RATE * hz + ph]))
-    return bool((t < 2.0 ** 24).all() and (np.abs(dr) <= 0.25).all() and (np.abs(np.sin(2 * np.pi * dr)) >= 1e-3).all()
+    return bool((t < 2.0 ** 26).all() and (np.abs(dr) <= 0.25).all() and (np.abs(np.sin(2 * np.pi * dr)) >= 1e-3).all()
                 and (N >= ctx or first_frame >= ctx))
 
 
@@ -62,48 +78,51 @@ def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2, 
     vpt, span = _native.fused_geometry(voices, N, K, ctx)
     sink = bus_channels + bus_channels / vpt if name == 'fused_voice_bus' else 2.0
     if steady and name == 'fused_voice_bus':
-        # launch_voice_bus: the closed-form kernel takes 8 voices per lane when that still leaves a wave per SIMD
-        if vpt == 4 and -(-voices // 512) * -(-K // span) >= 1024:
-            vpt = 8
+        plan = _native.fused_voice_bus_plan('Sine', ctx, voices, N, K, ctx)
+        vpt, span = plan['voices_per_lane'], plan['blocks_per_lane']
         return 5.0 + bus_channels + bus_channels / vpt, vpt, span
     return 2.0 * (span * N + ctx) / (span * N) + 4.0 * (N + ctx) / N + sink, vpt, span
 
 
-def synth_params(total_voices: int):
-    rng = np.random.default_rng(0)
-    hertz = rng.uniform(55, 1760, size=(1, total_voices))
-    phase = rng.uniform(0, 1, size=(1, total_voices))
-    cutoff = rng.uniform(200, 8000, size=(1, total_voices))
-    gain = rng.uniform(0, 1, size=(1, total_voices)) / total_voices
-    theta = rng.uniform(0, np.pi / 2, size=total_voices)
-    pan = np.stack([np.cos(theta), np.sin(theta)])
-    return dict(hertz=hertz, phase=phase, cutoff=cutoff, gain=gain, pan=pan)
+def kernel_table(summ: dict, bytes_per_unit) -> dict:
+    """per engine launch name: calls, average HIP-event time, share of the timed GPU time, algorithmic GB/s"""
+    total_ms = sum(e['ms'] for e in summ.values()) or 1.0
+    table = {}
+    for name, e in summ.items():
+        bpu = bytes_per_unit(name)
+        avg_ms = e['ms'] / e['calls']
+        table[name] = {'calls': e['calls'], 'avg_ms': avg_ms, 'share': e['ms'] / total_ms,
+                       'algo_bytes_per_voice_sample': bpu,
+                       'algo_GBs': (bpu or 0) * (e['units'] / e['calls']) / (avg_ms * 1e-3) / 1e9}
+    return table
 
 
-def build_graph(p, lo, hi):
-    from signals_amd.chain.ext import SumBus
-    from signals_amd.chain.fixed import Fixed
-    from signals_amd.chain.fx import Gain, LowPass
-    from signals_amd.chain.osc import Sine
+def hbm_roofline(kernels: dict, dom: str, traffic) -> dict:
+    k = kernels[dom]
+    return {'bound': 'hbm', 'kernel': dom, 'achieved': k['algo_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': k['algo_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
+            'algo_bytes_per_voice_sample': k['algo_bytes_per_voice_sample'], 'avg_launch_ms': k['avg_ms']}
 
-    def fixed(v):
-        f = Fixed()
-        f.get_state().value = np.ascontiguousarray(v)
-        return f
 
-    osc = Sine()
-    osc.hertz = fixed(p['hertz'][:, lo:hi])
-    osc.phase = fixed(p['phase'][:, lo:hi])
-    lp = LowPass()
-    lp.input = osc
-    lp.cutoff = fixed(p['cutoff'][:, lo:hi])
-    g = Gain()
-    g.left = lp
-    g.right = fixed(p['gain'][:, lo:hi])
-    bus = SumBus()
-    bus.input = g
-    bus.get_state().gains = np.ascontiguousarray(p['pan'][:, lo:hi])
-    return bus
+def valu_roofline(kernels: dict, dom: str, units_per_call: float, ops: float, traffic, detail: dict) -> dict:
+    """a fused voice kernel: f64 VALU instruction-lanes per second against the chip's f64 vector issue peak; the HBM
+    view of the same launch (it moves almost nothing) is nested under `hbm`"""
+    k = kernels[dom]
+    ach = ops * units_per_call / (k['avg_ms'] * 1e-3) / 1e12
+    return {'bound': 'valu_f64', 'kernel': dom, 'achieved': ach, 'peak': F64_VALU_PEAK, 'unit': 'T f64-instr-lanes/s',
+            'frac': ach / F64_VALU_PEAK, 'traffic': traffic, 'f64_ops_per_voice_sample': ops,
+            'avg_launch_ms': k['avg_ms'], **detail,
+            'hbm': {'achieved': k['algo_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k['algo_GBs'] / HBM_PEAK_GBS,
+                    'algo_bytes_per_voice_sample': k['algo_bytes_per_voice_sample'],
+                    'note': 'SURVEY.md 8d: the fused lower bound is ~16/V B per voice-sample, so this launch is f64-VALU-bound '
+                            'by construction; the HBM-bound node-materialised schedule is under alt_schedule'}}
+
+
+def pmc_traffic(family: str):
+    tfile = ROOT / 'profiles' / 'traffic.json'
+    if tfile.exists():
+        return json.loads(tfile.read_text()).get(family)
+    return None
 
 
 def cpu_baseline(p, voices, frames, budget_s=12.0):
@@ -112,26 +131,42 @@ def cpu_baseline(p, voices, frames, budget_s=12.0):
     from oracle import chain_ref as R
     import warnings
     warnings.filterwarnings('ignore', category=DeprecationWarning)
-    sl = slice(0, voices)
-    node = R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(p['hertz'][:, sl]), R.Fixed(p['phase'][:, sl])),
-                                     R.Fixed(p['cutoff'][:, sl])), R.Fixed(p['gain'][:, sl]))
-    pan = p['pan'][:, sl]
+    node, pan = cfg.c2_oracle(p, 0, voices)
     t0 = time.perf_counter()
     blocks = 0
-    kept = []                                   # the first blocks' stereo bus, for the max-abs-error leg
     while True:
-        bus = R.sum_bus(R.render(node, blocks * frames, frames, voices, RATE), pan)
-        if blocks < 8:
-            kept.append(bus)
+        R.sum_bus(R.render(node, blocks * frames, frames, voices, RATE), pan)
         blocks += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or blocks >= 64:
             break
-    cpu_baseline.reference_bus = np.concatenate(kept)
     return dict(value=voices * frames * blocks / dt / 1e6, unit='Msamples/s', cores=1, kind='port',
                 sample=f'{blocks} consecutive {frames}-frame blocks of the {voices}-voice C2 graph from position 0, '
                        f'{dt:.1f} s, oracle/chain_ref.py (numpy {np.__version__}, scipy butter+sosfilt per channel per block), '
                        f'host has {os.cpu_count()} logical cores')
+
+
+def oracle_bus_blocks(p, voices, frames, positions):
+    """float32(oracle float64) stereo bus of the C2 graph for the blocks starting at `positions` (the single-filter graph
+    is position-pure: any block can be rendered on its own, fx.py:85-106)"""
+    from oracle import chain_ref as R
+    import warnings
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    node, pan = cfg.c2_oracle(p, 0, voices)
+    return {pos: R.sum_bus(R.render(node, pos, frames, voices, RATE), pan).astype(np.float32).astype(np.float64)
+            for pos in positions}
+
+
+def check_batch_against_oracle(p, voices, frames, batch: torch.Tensor, batch_position: int, nblocks: int, indices):
+    """max |GPU - float32(oracle)| per checked block of ONE rendered batch (rows = nblocks*frames from batch_position)"""
+    indices = sorted({b for b in indices if 0 <= b < nblocks})
+    ref = oracle_bus_blocks(p, voices, frames, [batch_position + b * frames for b in indices])
+    got = batch.double().cpu().numpy()
+    per_block = {}
+    for b in indices:
+        per_block[str(b)] = float(np.max(np.abs(got[b * frames:(b + 1) * frames] - ref[batch_position + b * frames])))
+    scale = float(max(np.max(np.abs(r)) for r in ref.values()))
+    return per_block, scale
 
 
 def _cpu_worker(args):
@@ -139,12 +174,10 @@ def _cpu_worker(args):
     from oracle import chain_ref as R
     import warnings
     warnings.filterwarnings('ignore', category=DeprecationWarning)
-    sl = slice(lo, hi)
-    node = R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(p['hertz'][:, sl]), R.Fixed(p['phase'][:, sl])),
-                                     R.Fixed(p['cutoff'][:, sl])), R.Fixed(p['gain'][:, sl]))
+    node, pan = cfg.c2_oracle(p, lo, hi)
     acc = 0.0
     for b in range(blocks):
-        acc += float(R.sum_bus(R.render(node, b * frames, frames, hi - lo, RATE), p['pan'][:, sl]).sum())
+        acc += float(R.sum_bus(R.render(node, b * frames, frames, hi - lo, RATE), pan).sum())
     return acc
 
 
@@ -165,6 +198,76 @@ def cpu_baseline_sharded(p, voices, frames, workers, blocks=128):
                        f'{workers} processes, {dt:.1f} s')
 
 
+# --------------------------------------------------------------------------------------------------- other configs
+def run_config(name: str, steps: int = 12) -> dict:
+    """BASELINE.json's C3 / C5 on this GPU through the engine's default schedule: throughput, per-kernel table, the
+    dominant kernel's roofline, and max-abs error of the first rendered batch (the timed launch geometry) against the
+    CPU oracle on whole-width blocks."""
+    from oracle import chain_ref as R
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    import warnings
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    if name == 'C3':
+        V, channels, N, K = 1024, 1, 1024, 256
+        p = cfg.c3_params(V)
+        node, workload = cfg.c3_graph(p), f'C3: {V}-voice Sawtooth->LowPass->LowPass->(x ADSR)->SumBus(mono), 48 kHz, {N}-frame blocks, {K} blocks per batch'
+    else:
+        V, channels, N, K = 4096, 4096, 256, 64
+        p = cfg.c5_params(V)
+        node, workload = cfg.c5_graph(p), f'C5: {V}-voice Sine->LowPass->MixMatrix(64x64), 48 kHz, {N}-frame blocks, {K} blocks per batch'
+    timer = KernelTimer()
+    r = BatchRenderer(node, channels, RATE, timer=timer)
+    first = r.render(0, N, K)
+    if name == 'C3':
+        # cascaded filters depend on the render history (SURVEY.md 8a A9): the oracle renders sequentially from 0
+        ref = R.sum_bus(R.render_stream(cfg.c3_oracle(p), 0, N, 2, V)).astype(np.float32).astype(np.float64)
+        got = first[:2 * N].double().cpu().numpy()
+        errs = {str(b): float(np.max(np.abs(got[b * N:(b + 1) * N] - ref[b * N:(b + 1) * N]))) for b in (0, 1)}
+        sample = f'mono bus, blocks 0 and 1 of the first {K}-block batch (all {V} voices) vs the CPU oracle rendered sequentially from 0'
+    else:
+        oracle = cfg.c5_oracle(p)
+        errs = {}
+        for b in (0, K - 1):
+            ref = R.render(oracle, b * N, N, V, RATE).astype(np.float32).astype(np.float64)
+            errs[str(b)] = float(np.max(np.abs(first[b * N:(b + 1) * N].double().cpu().numpy() - ref)))
+        sample = f'all {V} mixed voices, blocks 0 and {K - 1} of the first {K}-block batch vs the CPU oracle'
+    del first
+    pos = N * K
+    for _ in range(2):
+        r.render(pos, N, K); pos += N * K
+    torch.cuda.synchronize(); timer.reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r.render(pos, N, K); pos += N * K
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    summ = timer.summary()
+    kernels = kernel_table(summ, lambda k: ALGO_BYTES.get(k.split('[')[0]))
+    dom = max(summ, key=lambda k: summ[k]['ms'])
+    fam = dom.split('[')[0]
+    from signals_amd import _native
+    model = _native.fused_cascade_model(V, N, K) if fam == 'fused_cascade_bus' and hasattr(_native, 'fused_cascade_model') else None
+    if model is not None:
+        roof = valu_roofline(kernels, dom, summ[dom]['units'] / summ[dom]['calls'], model['f64_ops_per_voice_sample'],
+                             pmc_traffic(fam), {k: v for k, v in model.items() if k != 'f64_ops_per_voice_sample'})
+    else:
+        roof = hbm_roofline(kernels, dom, pmc_traffic(f'{name}/{fam}'))
+        if fam == 'fused_osc_biquad_mix':
+            roof['mfma'] = {'flop_per_voice_sample': 128, 'achieved_TFLOPs': 128 * V * N * K / (kernels[dom]['avg_ms'] * 1e-3) / 1e12,
+                            'peak_TFLOPs': 157.3, 'note': 'exact-f32 v_mfma_f32_32x32x2_f32; 16 flop/B: below the f32-MFMA ridge, '
+                                                          'the launch is the walker (f64 VALU) plus the MFMAs, which do not overlap on a SIMD'}
+    full_scale = float(np.max(np.abs(ref)))
+    return {'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
+            'steps': steps, 'roofline': roof, 'kernels': kernels,
+            'max_abs_error': {'per_block': errs, 'max': max(errs.values()), 'full_scale': full_scale,
+                              'max_relative_to_full_scale': max(errs.values()) / max(1.0, full_scale),
+                              'bar': '1e-6 of full scale: the outputs are sums over voices (full scale > 1), stored as float32 '
+                                     '(one ulp at full scale = %.1e); C5 contracts in exact-f32 MFMA as BASELINE config 5 defines it. '
+                                     'Both nodes are build-defined (SURVEY.md 8a A11): parity is against the oracle definition'
+                                     % float(np.spacing(np.float32(full_scale))),
+                              'sample': sample}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -177,10 +280,12 @@ def main():
     ap.add_argument('--voices', type=int, default=1024, help='voices per GPU')
     ap.add_argument('--frames', type=int, default=256)
     ap.add_argument('--position', type=int, default=0)
+    ap.add_argument('--sustained-s', type=float, default=2.0, help='length of the sustained leg (0 disables)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the C3 / C5 legs')
     ap.add_argument('--materialised', action='store_true', help='headline = one kernel per node (no fusion)')
-    ap.add_argument('--single-mode', action='store_true', help='skip the second (alternative schedule) measurement')
+    ap.add_argument('--single-mode', action='store_true', help='only the headline measurement (profiling runs)')
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints its version banner to stdout (fd 1) when the first
@@ -201,6 +306,7 @@ def main():
     from signals_amd import parallel
     from signals_amd.engine import KernelTimer
     parallel.init_process_group()                        # RCCL (backend "nccl") when WORLD_SIZE > 1
+    backend = dist.get_backend() if dist.is_initialized() else None
     V, N, K = args.voices, args.frames, args.blocks
     params = synth_params(V * world)
 
@@ -210,8 +316,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(fuse: bool, steps: int, warmup: int) -> dict:
-        """W untimed + exactly `steps` timed batches of this rank's 1024-voice graph (+ bus all-reduce)"""
+    def measure(fuse: bool, steps: int, warmup: int, sustained_s: float = 0.0) -> dict:
+        """W untimed + exactly `steps` timed batches of this rank's 1024-voice graph (+ bus reduce); then, optionally,
+        the same steps for `sustained_s` more seconds"""
         timer = None if args.no_kernel_timing else KernelTimer()
         renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
                                             rate=RATE, timer=timer, fuse=fuse)
@@ -220,7 +327,7 @@ def main():
         pending = None
 
         def step():
-            # (K*N, 2) f32 bus: local render, then the RCCL all-reduce of THIS batch is left in flight on
+            # (K*N, 2) f32 bus: local render, then the RCCL reduce of THIS batch is left in flight on
             # RCCL's stream while the next batch renders; it is waited for one step later (and at the fence)
             nonlocal pos, pending
             bus, work = renderer.render_async(pos, N, K, dst=0)        # the sink lives on rank 0: reduce, not all-reduce
@@ -255,8 +362,10 @@ def main():
             bus = step()
         if pending is not None:
             pending.wait()
+            pending = None
         fence()
         dt = time.perf_counter() - t0
+        last_position = pos - N * K                          # where the batch in `bus` starts
         runtime.check_status()
         assert torch.isfinite(bus).all()
         if world > 1:
@@ -264,55 +373,58 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         samples = V * world * N * K * steps
-        res = {'value': samples / dt / 1e6, 'ms_per_step': dt / steps * 1e3}
+        res = {'value': samples / dt / 1e6, 'ms_per_step': dt / steps * 1e3, 'last_bus': bus, 'last_position': last_position}
         if timer:
             summ = timer.summary()
-            total_ms = sum(e['ms'] for e in summ.values())
-            kernels = {}
             closed = fuse and steady_applies(params, rank * V, (rank + 1) * V, args.position,
                                              args.position + (warmup + steps) * N * K - 1, N)
-            for name, e in summ.items():
-                bpu = ALGO_BYTES.get(name.split('[')[0], 0)
-                if name.split('[')[0] == 'fused_voice_bus':
+
+            def bytes_per_unit(kname):
+                fam = kname.split('[')[0]
+                if fam == 'fused_voice_bus':
                     vpl = fused_f64_ops_per_voice_sample('fused_voice_bus', V, N, K, steady=closed)[1]
                     tiles = -(-V // (64 * vpl))                     # one f64 partial per (voice tile, frame, channel), written and re-read
-                    bpu = (tiles * 2 * 8 * 2 + 2 * 4) / V
-                avg_ms = e['ms'] / e['calls']
-                kernels[name] = {'calls': e['calls'], 'avg_ms': avg_ms, 'share': e['ms'] / total_ms,
-                                 'algo_bytes_per_voice_sample': bpu,
-                                 'algo_GBs': bpu * (e['units'] / e['calls']) / (avg_ms * 1e-3) / 1e9}
+                    return (tiles * 2 * 8 * 2 + 2 * 4) / V
+                return ALGO_BYTES.get(fam, 0)
+            kernels = kernel_table(summ, bytes_per_unit)
             dom = max(summ, key=lambda k: summ[k]['ms'])
-            traffic = None
-            tfile = ROOT / 'profiles' / 'traffic.json'
-            if tfile.exists():
-                traffic = json.loads(tfile.read_text()).get(dom.split('[')[0])
-            res['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['algo_GBs'],
-                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['algo_GBs'] / HBM_PEAK_GBS,
-                               'traffic': traffic,
-                               'algo_bytes_per_voice_sample': kernels[dom]['algo_bytes_per_voice_sample'],
-                               'avg_launch_ms': kernels[dom]['avg_ms']}
-            if dom.split('[')[0] in FUSED_KERNELS:
-                # f64-VALU-bound by construction (the fused lower bound is 16/V B per voice-sample):
-                # the meaningful ceiling is the f64 vector issue rate,
-                # peak = 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39.3 T instr-lanes/s (= 78.6 TFLOP/s FMA)
-                ops, vpt, span = fused_f64_ops_per_voice_sample(dom.split('[')[0], V, N, K, steady=closed)
-                ach = ops * (summ[dom]['units'] / summ[dom]['calls']) / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
-                res['roofline']['valu_f64'] = {'achieved': ach, 'peak': 39.3, 'unit': 'T f64-instr-lanes/s',
-                                               'frac': ach / 39.3, 'f64_ops_per_voice_sample': ops,
-                                               'voices_per_lane': vpt, 'blocks_per_lane': span,
-                                               'path': 'closed form: steady-state sinusoid + homogeneous transient per '
-                                                       'block, no warm-up rows (fused_steady_bus_kernel)' if closed
-                                                       else 'span walker (fused_walk_kernel)'}
-                res['roofline']['launches'] = ('avg_launch_ms brackets everything sig_fused_voice_bus enqueues: the chain '
-                                               'kernel and the tile sum (sig_bus::partials_kernel), plus steady_prep_kernel '
-                                               "on the calls where the per-voice constants change; the chain kernel's own "
-                                               'duration is in profiles/*_kernel_stats.csv')
-                res['roofline']['note'] = ('this kernel is f64-VALU-bound, not HBM-bound: see valu_f64; the HBM-bound '
-                                           'node-materialised schedule is reported under alt_schedule')
+            fam = dom.split('[')[0]
+            if fam in VALU_BOUND:
+                ops, vpt, span = fused_f64_ops_per_voice_sample(fam, V, N, K, steady=closed)
+                plan = _native.fused_voice_bus_plan('Sine', args.position + N * K, V, N, K, 100)
+                res['roofline'] = valu_roofline(kernels, dom, summ[dom]['units'] / summ[dom]['calls'], ops, pmc_traffic(fam), {
+                    'voices_per_lane': vpt, 'blocks_per_lane': span, 'device_kernel': plan['kernel'].replace('C>', '2>'),
+                    'path': 'closed form: steady-state sinusoid + homogeneous transient per block, no warm-up rows '
+                            '(fused_steady_bus_kernel); only constant-parameter Sine->LowPass|HighPass->[Gain]->SumBus takes it: '
+                            'other oscillators run the span walker (~2.0 T voice-samples/s), interposed effects or modulated '
+                            'controls run per-node kernels' if closed else 'span walker (fused_walk_kernel)',
+                    'launches': 'avg_launch_ms brackets everything sig_fused_voice_bus enqueues: the chain kernel and the tile sum '
+                                '(sig_bus::partials_kernel), plus steady_prep_kernel on the calls where the per-voice constants '
+                                "change; the chain kernel's own duration is in profiles/*_kernel_stats.csv"})
+            else:
+                res['roofline'] = hbm_roofline(kernels, dom, pmc_traffic(fam))
             res['kernels'] = kernels
+        if sustained_s > 0 and world == 1:
+            # at 1.07 G voice-samples per 0.33 ms this leg covers DAYS of audio; a real stream is nowhere near the
+            # 2^26-cycle hand-over of the closed form (10.6 h at 1760 Hz), so the stream position wraps every `wrap` batches
+            n = max(steps, int(sustained_s / (dt / steps)) + 1)
+            wrap = max(1, min(1024, int(2.0 ** 26 / 1760.0 * RATE) // (N * K) - 1))
+            renderer.renderer.timer = None                    # no HIP events: thousands of un-synchronised steps
+            fence()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if i % wrap == 0:
+                    pos = args.position
+                step()
+            fence()
+            ds = time.perf_counter() - t0
+            res['sustained'] = {'seconds': ds, 'steps': n, 'Msamples_per_s': V * N * K * n / ds / 1e6, 'ms_per_step': ds / n * 1e3,
+                                'note': f'same steps back to back; the stream position restarts every {wrap} batches '
+                                        f'({wrap * N * K / RATE / 3600:.1f} h of audio)'}
         return res
 
-    main_mode = measure(fuse=not args.materialised, steps=args.steps, warmup=args.warmup)
+    main_mode = measure(fuse=not args.materialised, steps=args.steps, warmup=args.warmup,
+                        sustained_s=0.0 if args.single_mode else args.sustained_s)
     other = None
     if not args.single_mode:
         other = measure(fuse=args.materialised, steps=max(3, args.steps // 2), warmup=min(2, args.warmup))
@@ -364,6 +476,10 @@ def main():
             us = (time.perf_counter() - t0) / 200 * 1e6
             latency[name] = {'us_per_block': us, 'Msamples_per_s': V * N / us, 'x_realtime': (N / RATE * 1e6) / us}
 
+    configs = None
+    if world == 1 and not args.single_mode and not args.no_configs and not args.no_cpu_baseline:
+        configs = {name: run_config(name) for name in ('C3', 'C5')}
+
     if rank == 0:
         def describe(fused):
             return ('fused voice chain + bus: sig_fused_voice_bus (Sine->LowPass->Gain->SumBus in one chain launch plus a '
@@ -382,36 +498,50 @@ def main():
                                    f'{N}-frame blocks, {K} blocks per batch (f32 storage, f64 phase/recurrence); '
                                    f'engine schedule = {describe(not args.materialised)}',
                        'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
-                       'parallelism': f'voices sharded {V}/GPU x{world}, RCCL reduce of the stereo bus to rank 0, async'},
+                       'parallelism': f'voices sharded {V}/GPU x{world}; '
+                                      + (f'torch.distributed backend {backend} (RCCL), {world} ranks: one async reduce of the '
+                                         f'stereo bus to rank 0 per batch' if backend else 'single process, no collective'),
+                       'rccl_ranks': world if backend == 'nccl' else 0, 'dist_backend': backend},
         }
-        for k in ('roofline', 'kernels'):
+        for k in ('roofline', 'kernels', 'sustained'):
             if k in main_mode:
                 line[k] = main_mode[k]
         if other is not None:
-            other['schedule'] = describe(args.materialised)
+            alt = {k: v for k, v in other.items() if k not in ('last_bus', 'last_position')}
+            alt['schedule'] = describe(args.materialised)
             if not args.materialised:
                 # SURVEY.md 8d's whole-graph view of the per-node schedule: 24 algorithmic bytes per voice-sample
-                other['hbm_frac_at_24_bytes_per_voice_sample'] = other['value'] * 1e6 * 24 / (HBM_PEAK_GBS * 1e9)
-            line['alt_schedule'] = other
+                alt['hbm_frac_at_24_bytes_per_voice_sample'] = other['value'] * 1e6 * 24 / (HBM_PEAK_GBS * 1e9)
+            line['alt_schedule'] = alt
         if by_batch:
             line['fused_schedule_at_other_batch_sizes'] = by_batch
         if latency is not None:
             line['latency_mode'] = latency
         if not args.no_cpu_baseline and world == 1:
+            # BASELINE.json's second metric, on the output of the LAST TIMED batch of each schedule: blocks 0..7, the middle
+            # one and the last one against float32(oracle float64); the batch starts (warmup + steps - 1) batches into the stream
+            errors = {}
+            for label, mode, picks in (('materialised' if args.materialised else 'fused', main_mode, list(range(8)) + [K // 2, K - 1]),
+                                       ('fused' if args.materialised else 'materialised', other, [0, K // 2, K - 1])):
+                if mode is None:
+                    continue
+                per_block, scale = check_batch_against_oracle(params, V, N, mode['last_bus'], mode['last_position'], K, picks)
+                errors[label] = {'max': max(per_block.values()), 'per_block': per_block, 'batch_position': mode['last_position']}
+                errors['full_scale'] = scale
+            plan = _native.fused_voice_bus_plan('Sine', main_mode['last_position'], V, N, K, 100)
+            closed = steady_applies(params, 0, V, main_mode['last_position'], main_mode['last_position'] + N * K - 1, N)
+            line['max_abs_error'] = dict(
+                errors, bar=1e-6,
+                fused_kernel=(plan['kernel'].replace('C>', '2>') if closed or not plan['closed_form'] else 'fused_steady_bus_kernel: per-wave fallback'),
+                fused_launch=f"fused_voice_bus[Sine,lp,gain]: {plan['voices_per_lane']} voices x {plan['blocks_per_lane']} blocks per lane",
+                sample=f'stereo bus of the last timed {K}-block batch of the {V}-voice graph (its own output tensor), whole '
+                       f'blocks against the CPU oracle rendering the same frame positions')
             line['cpu_baseline'] = cpu_baseline(params, V, N)
-            # BASELINE.json's second metric: max-abs sample error of the rendered bus against float32(oracle float64)
-            from signals_amd.engine import BatchRenderer
-            ref = cpu_baseline.reference_bus.astype(np.float32).astype(np.float64)
-            nb = ref.shape[0] // N
-            errs = {}
-            for label, fuse in (('fused', True), ('materialised', False)):
-                got = BatchRenderer(build_graph(params, 0, V), 2, RATE, fuse=fuse).render(0, N, nb).double().cpu().numpy()
-                errs[label] = float(np.max(np.abs(got - ref)))
-            line['max_abs_error'] = dict(errs, bar=1e-6, full_scale=float(np.max(np.abs(ref))),
-                                         sample=f'stereo bus of the first {nb} blocks of the {V}-voice graph vs the CPU oracle')
             workers = min(16, os.cpu_count() or 1)                      # the GPU box's CPU share for one GPU
             if workers > 1 and V % workers == 0:
                 line['cpu_baseline_sharded'] = cpu_baseline_sharded(params, V, N, workers)
+        if configs:
+            line['configs'] = configs
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist.is_initialized():

@@ -224,6 +224,19 @@ int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t 
  * constants of the closed form (steady-state sinusoid + homogeneous transient per cold-started block; voices it does
  * not cover are walked row by row in the same launch) into the tail of the workspace.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
+/* sig_fused_voice_bus restricted to the row-by-row span walker (never the Sine closed form).  The closed form, like
+ * the walker's incremental Sine phase, holds while |t| = |frame / rate * hertz + phase| < 2^26 cycles (past that the
+ * reference's own rounding of t, which neither reproduces, approaches the 1e-6 bar): a wave with a voice beyond it is
+ * done inside the closed-form launch by a plain per-row fallback that is correct but ~40x slower, fine for a few
+ * waves.  A caller that knows a whole launch lies beyond the limit (max |hertz| and the position are host-side
+ * knowledge) calls this entry instead: the walker's exact-phase path runs at about a third of the closed form's rate. */
+int sig_fused_voice_bus_walk(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                             const double* cutoff, int32_t cutoff_stride,
+                             const double* gain, int32_t gain_stride,
+                             const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                             double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
 /* sig_fused_voice_bus with the per-voice constants of its Sine closed form (filter design, H(e^{j theta}), the
  * block-start matrices: ~5 us of kernel time per call) kept by the caller across calls: `consts` is a device buffer of
  * sig_fused_voice_consts_size(voices) bytes; consts_ready == 0 fills it (and uses it), consts_ready != 0 skips that.

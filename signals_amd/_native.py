@@ -21,6 +21,7 @@ FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
 ABI_VERSION = 4
+SINE_FAST_MAX_CYCLES = 2.0 ** 26     # sig_osc.h kSineFastMaxT: |t| up to which the fused Sine kernels advance the phase incrementally
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
            'sig_white_noise', 'sig_adsr', 'sig_mix_matrix', 'sig_fused_osc_biquad',
@@ -28,7 +29,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
            'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
            'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
-           'sig_fused_voice_bus_plan', 'sig_fused_set_tuning')
+           'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk')
 
 
 class NativeError(RuntimeError):
@@ -79,6 +80,8 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus.restype = ctypes.c_int
         L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                           dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_voice_bus_walk.restype = ctypes.c_int
+        L.sig_fused_voice_bus_walk.argtypes = L.sig_fused_voice_bus.argtypes
         L.sig_fused_voice_consts_size.restype = ctypes.c_int64
         L.sig_fused_voice_consts_size.argtypes = [i32]
         L.sig_fused_voice_bus_prepared.restype = ctypes.c_int
@@ -144,7 +147,13 @@ def _gpu(*tensors: torch.Tensor) -> None:
             raise NativeError('HIP kernels need tensors resident on an MI355X (got a CPU tensor); no CPU fallback')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    """the hipStream_t torch currently launches on for `t`'s device"""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)              # the same handle as below, without building a Stream object
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -455,6 +464,46 @@ def latency_voice_bus(btype: str, rate: int, position, block_frames: int, contex
     return out
 
 
+class LatencyVoiceBusCall:
+    """`latency_voice_bus` with everything but the position and the output buffer validated and converted ONCE: the
+    per-block host path of latency mode is then one ctypes call (the tensors are kept alive by this object)."""
+
+    def __init__(self, btype: str, rate: int, block_frames: int, context: int, voices: int,
+                 hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
+                 bus_gains: torch.Tensor | None, bus_channels: int, workspace: torch.Tensor,
+                 status: torch.Tensor | None = None):
+        _gpu(hertz, phase, cutoff, gain, bus_gains, workspace, status)
+        need = lib().sig_latency_voice_bus_workspace(voices, block_frames, bus_channels)
+        if workspace.dtype != torch.float64 or workspace.numel() * 8 < need:
+            raise NativeError(f'latency workspace needs {need} bytes of float64 (latency_voice_bus_workspace)')
+        ptrs = []
+        for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+            if row is not None and row.shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+            ptrs.extend(_ctrl_row(row, name))
+        gp, gld = None, 0
+        if bus_gains is not None:
+            if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus_channels, voices) or bus_gains.stride(1) != 1:
+                raise NativeError(f'bus gains must be float64 ({bus_channels},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+            gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+        elif bus_channels != 1:
+            raise NativeError('a bus without gains is mono')
+        self._keep = (hertz, phase, cutoff, gain, bus_gains, workspace, status)
+        self._fn = lib().sig_latency_voice_bus
+        self._head = (FILT_TYPES[btype], rate)
+        self._mid = (block_frames, context, voices, *ptrs, gp, gld, bus_channels, workspace.data_ptr())
+        self._status = status.data_ptr() if status is not None else None
+        self.shape = (block_frames, bus_channels)
+        self.device = workspace.device
+
+    def __call__(self, position: int, out: torch.Tensor) -> torch.Tensor:
+        """`out`: a contiguous float32 (block_frames, bus_channels) tensor on the launch device"""
+        err = self._fn(*self._head, position, None, *self._mid, out.data_ptr(), self.shape[1], self._status, _stream(out))
+        if err:
+            raise NativeError(f'sig_latency_voice_bus failed: hipError_t {err}')
+        return out
+
+
 def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -> tuple[int, int]:
     """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
     vpt, span = ctypes.c_int32(), ctypes.c_int32()
@@ -512,10 +561,12 @@ def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frame
                     voices: int, hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor,
                     gain: torch.Tensor | None, bus_gains: torch.Tensor | None, out: torch.Tensor,
                     workspace: torch.Tensor | None = None, status: torch.Tensor | None = None,
-                    consts: torch.Tensor | None = None, consts_ready: bool = False) -> torch.Tensor:
+                    consts: torch.Tensor | None = None, consts_ready: bool = False, walk: bool = False) -> torch.Tensor:
     """out (nblocks*block_frames, bus_channels) f32 <- sum over voices of pan * [gain *] Filter(Osc).
     `consts`: a float64 device buffer of sig_fused_voice_consts_size(voices) bytes the caller keeps across calls for
-    the Sine closed form's per-voice constants; `consts_ready`: it already holds them for these parameters."""
+    the Sine closed form's per-voice constants; `consts_ready`: it already holds them for these parameters.
+    `walk`: the row-by-row span walker only (sig_fused_voice_bus_walk): for launches the caller knows to lie beyond the
+    closed form's phase range (SINE_FAST_MAX_CYCLES)."""
     _gpu(hertz, phase, cutoff, gain, bus_gains, out, status, consts)
     _audio(out, 'fused bus out')
     rows, bus = out.shape
@@ -534,6 +585,12 @@ def fused_voice_bus(kind: str, btype: str, rate: int, position: int, block_frame
     need = lib().sig_fused_voice_bus_workspace(voices, rows, bus)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    if walk:
+        _check(lib().sig_fused_voice_bus_walk(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
+                                              voices, *ptrs, gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
+                                              status.data_ptr() if status is not None else None, _stream(out)),
+               'sig_fused_voice_bus_walk')
+        return out
     if consts is not None:
         if consts.dtype != torch.float64 or consts.numel() * 8 < lib().sig_fused_voice_consts_size(voices):
             raise NativeError('consts must be float64 of sig_fused_voice_consts_size(voices) bytes')

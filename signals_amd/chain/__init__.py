@@ -31,6 +31,7 @@ from signals_amd.chain.nodes import (  # noqa: F401
     Emitter,
     ExplicitChannels,
     ExplicitChannelsEmitter,
+    HostSnapshot,
     ImplicitChannels,
     PassThroughResult,
     Receiver,

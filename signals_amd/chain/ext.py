@@ -12,6 +12,7 @@ from signals_amd import SignalFlags, _native, runtime
 from signals_amd.chain import (
     BadStateValue,
     BlockCachingEmitter,
+    HostSnapshot,
     ImplicitChannels,
     PassThroughResult,
     Receiver,
@@ -57,9 +58,9 @@ class SumBus(BlockCachingEmitter, Receiver):
         if gains is None:
             return None
         held = self._resident
-        if held is None or held[0] is not gains or not np.array_equal(held[1], gains):
+        if held is None or held[0] is not gains or not held[1].matches(gains):
             host = np.ascontiguousarray(gains, dtype=np.float64)
-            self._resident = held = (gains, host.copy(), torch.from_numpy(host.copy()).to(runtime.device()))
+            self._resident = held = (gains, HostSnapshot(gains), torch.from_numpy(host.copy()).to(runtime.device()))
         return held[2]
 
     def _eval(self, request: Request) -> torch.Tensor:
@@ -126,9 +127,9 @@ class MixMatrix(BlockCachingEmitter, Receiver):
     def resident_matrix(self) -> torch.Tensor:
         matrix = self._state.matrix
         held = self._resident
-        if held is None or held[0] is not matrix or not np.array_equal(held[1], matrix):
+        if held is None or held[0] is not matrix or not held[1].matches(matrix):
             host = np.ascontiguousarray(matrix, dtype=np.float32)
-            self._resident = held = (matrix, matrix.copy(), torch.from_numpy(host.copy()).to(runtime.device()))
+            self._resident = held = (matrix, HostSnapshot(matrix), torch.from_numpy(host.copy()).to(runtime.device()))
         return held[2]
 
     def _eval(self, request: Request) -> torch.Tensor:

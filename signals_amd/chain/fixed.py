@@ -4,8 +4,6 @@
 are; the device copy is uploaded once and re-uploaded only when the array changes -- assignment of another
 array or an in-place edit, which is detected by comparing the array's bytes with a snapshot on every reply
 (arrays of every size: ~0.4 us for 1024 doubles, ~16 us for 70 000, proportional beyond)."""
-import ctypes
-
 import attr
 import numpy as np
 import torch
@@ -14,41 +12,12 @@ from signals_amd import SignalFlags, runtime
 from signals_amd.chain import (
     BadStateValue,
     Emitter,
+    HostSnapshot,
     Request,
     Shape,
     result_dtype,
     state,
 )
-
-_SMALL_BYTES = 1 << 15      # snapshots up to this size are kept as bytes (one memcpy + memcmp, ~0.4 us for 1024 doubles)
-_libc = ctypes.CDLL(None)
-_libc.memcmp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
-_libc.memcmp.restype = ctypes.c_int
-
-
-class _Snapshot:
-    """What a `Fixed` array held when it was uploaded, so that an in-place edit of ANY size is seen at the next reply
-    (the reference's `Fixed._eval` returns the live array, fixed.py:38-39, so it always sees them).  Bitwise
-    comparison: identical NaNs compare equal (no re-upload per reply), -0.0 differs from 0.0 (a harmless re-upload)."""
-    __slots__ = ('layout', 'data', 'ptr')
-
-    def __init__(self, value: np.ndarray):
-        self.layout = (value.shape, value.dtype, value.strides)
-        if value.nbytes <= _SMALL_BYTES:
-            self.data, self.ptr = value.tobytes(), 0
-        else:
-            self.data = np.ascontiguousarray(value).copy()
-            self.ptr = self.data.ctypes.data
-
-    def matches(self, value: np.ndarray) -> bool:
-        if (value.shape, value.dtype, value.strides) != self.layout:
-            return False
-        if self.ptr == 0:
-            return value.tobytes() == self.data
-        if value.flags.c_contiguous:
-            return _libc.memcmp(value.ctypes.data, self.ptr, value.nbytes) == 0
-        return np.ascontiguousarray(value).tobytes() == self.data.tobytes()
-
 
 def _validate_array(instance, attribute, new_value):
     if not (isinstance(new_value, np.ndarray) and new_value.ndim == 2):
@@ -91,7 +60,7 @@ class Fixed(Emitter):
         dtype = result_dtype(value.shape[0])
         host = np.ascontiguousarray(value, dtype=np.float64)
         tensor = torch.from_numpy(host.copy()).to(device=runtime.device(), dtype=dtype)
-        self._resident = (value, _Snapshot(value), tensor)
+        self._resident = (value, HostSnapshot(value), tensor)
         return tensor
 
     def _eval(self, request: Request) -> torch.Tensor:

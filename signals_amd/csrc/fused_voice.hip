@@ -15,7 +15,7 @@
 //     at its row -c, i.e. inside block b: its warm-up runs as a second recurrence on the oscillator sample the
 //     lane has just computed for block b, and becomes the output recurrence at the block boundary.  Every
 //     oscillator sample is computed once (not (N+c)/N times); the arithmetic of each chain is unchanged;
-//   * Sine, while every |t| of the span is < 2^24 cycles and the voice advances by at most a quarter turn per
+//   * Sine, while every |t| of the span is < 2^26 cycles and the voice advances by at most a quarter turn per
 //     row (|hertz| <= rate/4 after aliasing): the oscillator is the two-term recurrence in difference (Reinsch)
 //     form   x <- x + d;  d <- d - m x,   m = 4 sin^2(theta/2),  d_0 = 2 sin(theta/2) cos(phi_0 + theta/2),
 //     seeded once per span from the reference's own t at the span's first row (sin by the f64 polynomial).
@@ -77,6 +77,7 @@ struct FusedArgs {
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
     double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
+    int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
 };
 
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
@@ -309,7 +310,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             }
         };
         int done = 0;
-        // the exact-phase Sine path is the rare one (positions beyond 2^24 cycles): rolled loops, so that its
+        // the exact-phase Sine path is the rare one (positions beyond 2^26 cycles): rolled loops, so that its
         // register needs do not set the kernel's budget
         constexpr bool GROUPED = FAST || KIND != SIG_OSC_SINE;
         if (!OUT || !BUS) {
@@ -406,7 +407,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // launch's first block (c = min(ctx, position)).
 enum { SC_NA1, SC_NA2, SC_SCALE, SC_NM, SC_ST, SC_GR, SC_HRE, SC_HIM, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
 
-// per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^24 cycles over
+// per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^26 cycles over
 // the span (as for the walker's Sine recurrence), at most a quarter turn per row, and sin(theta) not tiny (the map
 // from (yss, dss) back to the complex amplitude divides by it: below ~8 Hz at 48 kHz the walker is used instead)
 __device__ __forceinline__ bool steady_voice_ok(double hz, double ph, double rate, double st, double q_first, double q_last) {
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
     put(SC_T0 + 0, T0.a); put(SC_T0 + 1, T0.b); put(SC_T0 + 2, T0.c); put(SC_T0 + 3, T0.d);
 }
 
-// The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^24 cycles), done inside the
+// The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^26 cycles), done inside the
 // same launch by the plainest possible code: every block on its own, exact per-row phase (one IEEE divide per row),
 // the b0-normalised recurrence from zero state over [c context rows | block], rows staged one at a time.  Rolled
 // loops and no row groups, so that this path does not set the kernel's register budget; ~4x slower per voice-sample
@@ -696,7 +697,7 @@ struct BusPlan { int vpt, span, steady; };
 BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
     BusPlan p{4, 1, 0};
     pick_geometry(a, 4, p.vpt, p.span);
-    if (kind == SIG_OSC_SINE && (a.N >= a.ctx || a.position >= a.ctx)) {       // at most the first block has a short context
+    if (kind == SIG_OSC_SINE && !a.force_walk && (a.N >= a.ctx || a.position >= a.ctx)) {   // at most the first block has a short context
         p.steady = tuning().steady < 0 ? 1 : tuning().steady;                  // tuning / test hook
         if (p.steady) {
             // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
@@ -1038,7 +1039,7 @@ int fused_voice_bus_impl(int osc_kind, int filt_type, int32_t rate, int64_t posi
                          const double* cutoff, int32_t cutoff_stride, const double* gain, int32_t gain_stride,
                          const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
                          double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
-                         double* consts, int32_t consts_ready)
+                         double* consts, int32_t consts_ready, int force_walk = 0)
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
@@ -1051,6 +1052,7 @@ int fused_voice_bus_impl(int osc_kind, int filt_type, int32_t rate, int64_t posi
                 nullptr, 0, 0, status};
     a.consts_ext = consts;
     a.consts_ready = consts_ready;
+    a.force_walk = force_walk;
     BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return gain ? dispatch_bus_kind<true>(osc_kind, bus_channels, a, bus, out, out_ld, s)
@@ -1069,6 +1071,19 @@ extern "C" int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, in
     return fused_voice_bus_impl(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride,
                                 phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
                                 bus_channels, workspace, out, out_ld, status, stream, nullptr, 0);
+}
+
+extern "C" int sig_fused_voice_bus_walk(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                        const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                        const double* cutoff, int32_t cutoff_stride,
+                                        const double* gain, int32_t gain_stride,
+                                        const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                        double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    return fused_voice_bus_impl(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride,
+                                phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
+                                bus_channels, workspace, out, out_ld, status, stream, nullptr, 0, 1);
 }
 
 extern "C" int64_t sig_fused_voice_consts_size(int32_t voices)

@@ -6,7 +6,7 @@
 //     solution of the cold start at r0 = p - c.  Both can be seeded at ANY row: yss from the phase of that row
 //     (sin by the f64 polynomial), yh = [A^(n - r0) (-sss_{r0-1})]_0 with A^k by squaring.  So a lane takes one voice
 //     and one chunk of kRows rows: ~600 f64 operations of set-up, then 7 per row.  voices/64 x N/kRows waves.
-//   * lanes whose voice the closed form does not cover (below ~8 Hz, above rate/4, past 2^24 cycles) walk from r0
+//   * lanes whose voice the closed form does not cover (below ~8 Hz, above rate/4, past 2^26 cycles) walk from r0
 //     to their chunk with the exact per-row phase and the driven recurrence -- slow, rare, same launch.
 //   * per-row voice sums through sig_bus::Tile into per-tile f64 partials; the LAST workgroup to finish (a ticket
 //     from one atomic counter) adds the tiles in fixed order, writes the float32 bus, re-arms the counter and, when

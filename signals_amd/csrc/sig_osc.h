@@ -87,9 +87,11 @@ __device__ __forceinline__ float osc_sine_f32(double t) {
 // advances by d = hertz/rate revolutions per row, so  t_j ~ t_0 + j*d  and only frac(t_0) (exact) and d are
 // needed.  Relative to the exact path this drops (a) the tracking of numpy's own argument rounding,
 // |fl(t*2pi) - 2pi*t| <= 9.4e-16*|t| rad, and (b) the roundings inside fl(fl(n/rate)*hertz)+phase, <= ulp(t)
-// cycles: both < 2.5e-8 rad while |t| < 2^24 cycles, which the caller checks per wave (kSineFastMaxT); beyond
-// that the exact path is used.  f_j = fma(j, d, f0) is a single rounding from exact operands, no accumulation.
-constexpr double kSineFastMaxT = 16777216.0;            // 2^24 cycles (2.6 h at 1760 Hz)
+// cycles: together <= 3 |t| 2^-53 cycles = 2.1e-15 |t| rad per row of reference rounding noise that the incremental
+// phase does not reproduce, plus the same bound once more for the seed (which carries the reference's rounding at the
+// span's first row): < 2.9e-7 while |t| < 2^26 cycles, a third of the 1e-6 bar, which the caller checks per wave
+// (kSineFastMaxT); beyond that the exact path is used.  f_j = fma(j, d, f0) is a single rounding from exact operands.
+constexpr double kSineFastMaxT = 67108864.0;            // 2^26 cycles (10.6 h at 1760 Hz, 56 min at 20 kHz)
 
 __device__ __forceinline__ float osc_sine_f32_fast(double f0, double d, double j) {
     const double f = fma(j, d, f0);                     // |f| <= 0.5 + 64*0.5

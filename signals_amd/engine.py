@@ -28,9 +28,13 @@ when nothing else consumes the intermediates; a graph that is exactly one such l
 call without re-walking it (latency mode).  `fuse=False` is one kernel per node and bit-identical to the
 eager path.
 
+Node classes without a kernel schedule (plugins, including ones written against the reference that
+answer numpy arrays) are pulled block by block through their own `respond()` and laid out as a batch
+buffer; everything downstream of them still runs one launch per node.
+
 Graphs that do not fit (a filter inside a control path, per-block ADSR / band-filter parameters,
-cascaded filters with N <= 100, unknown node classes) raise `NotBatchable`; callers fall back to the
-eager path (`BlockDriver` does so by itself).
+cascaded filters with N <= 100) raise `NotBatchable`; callers fall back to the eager path
+(`BlockDriver` does so by itself).
 """
 from __future__ import annotations
 
@@ -46,6 +50,8 @@ from signals_amd.chain import (
     Receiver,
     as_control,
     broadcast_shape,
+    graph_clock,
+    port,
 )
 from signals_amd.chain import ext, files, fixed, fx, noise, osc, shape
 
@@ -121,6 +127,17 @@ class _CapturedLaunches:
         return self.out
 
 
+class _EngineSink(Receiver):
+    """stands in for the consumer in requests the engine issues itself (plugin nodes pulled block by block)"""
+    input = port('input')
+    HOST_ARRAYS = False
+
+    @classmethod
+    def flags(cls):
+        from signals_amd import SignalFlags
+        return SignalFlags(0)
+
+
 class BatchRenderer:
     """Renders `node` (as seen through a request of `channels` channels at `rate`) in batches of consecutive
     blocks.  Keeps what a stream needs between batches: the last <=100 rows of every request-dependent
@@ -152,6 +169,7 @@ class BatchRenderer:
         self.latency_kernel = True                         # one-launch blocks for Sine chains in the latency regime
         self._replay = None                                # (graph version, N, K, launch(position)) of a one-launch plan
         self.scan_max_chains = SCAN_MAX_CHAINS             # latency regime threshold (tests set 0 to force the serial kernels)
+        self.requestor = _EngineSink()                     # the `requestor` of requests the engine itself issues to plugin nodes
 
     # ------------------------------------------------------------------ public
     def render(self, position: int, block_frames: int, nblocks: int) -> torch.Tensor:
@@ -159,7 +177,6 @@ class BatchRenderer:
         eager requests of `block_frames` frames."""
         if block_frames < 2:
             raise NotBatchable('block-rate (frames == 1) requests go through the eager path')
-        from signals_amd.chain import graph_clock
         if self._replay is not None:
             version, n, k, launch = self._replay
             if version == graph_clock.version and (n, k) == (block_frames, nblocks):
@@ -186,7 +203,6 @@ class BatchRenderer:
         self._captured = None
 
     def _remember_replay(self, N: int, K: int, launch) -> None:
-        from signals_amd.chain import graph_clock
         self._replay = (graph_clock.version, N, K, launch)
 
     # ------------------------------------------------------------------ kernel launch helper
@@ -246,6 +262,12 @@ def _modulated(node: Emitter | None) -> bool:
     return node is not None and any(not _ctl_const(p) for p in _control_ports(node))
 
 
+def _foreign(node: Emitter) -> bool:
+    """a node class the engine has no kernel schedule for -- a plugin written against the node API; it is pulled block by
+    block through its own respond(), so its reply may depend on the request like a filter's"""
+    return not isinstance(node, _KNOWN_TYPES)
+
+
 def _is_pure(node: Emitter | None, memo: dict) -> bool:
     """position-pure: no filter and no per-block control anywhere upstream on the audio path, so any row
     range can be rendered in one launch and history rows can simply be re-rendered"""
@@ -253,7 +275,7 @@ def _is_pure(node: Emitter | None, memo: dict) -> bool:
         return True
     if node not in memo:
         memo[node] = True       # cycles are rejected elsewhere
-        if isinstance(node, fx.CritFilter) or _modulated(node):
+        if isinstance(node, fx.CritFilter) or _modulated(node) or _foreign(node):
             memo[node] = False
         else:
             memo[node] = all(_is_pure(p.sig, memo) for p in _audio_ports(node))
@@ -385,7 +407,7 @@ class _Batch:
                     result = build(self, node, channels, hist, rows)
                     break
             else:
-                raise NotBatchable(f'no batched schedule for {node.cls_name()}')
+                result = self._sched_foreign(node, channels, hist, rows)
         if isinstance(result, tuple):                                          # a pass-through shares its input's buffer
             self._memo[key] = result
             return result
@@ -598,6 +620,31 @@ class _Batch:
             raise ValueError('all the input array dimensions except for the concatenation axis must match exactly')
         return torch.cat((left.to(AUDIO_DTYPE), right.to(AUDIO_DTYPE)), dim=1)     # buffer plumbing
 
+    def _sched_foreign(self, node, channels, hist, rows):
+        """A node class without a kernel schedule (a plugin, e.g. one written against the reference and answering numpy
+        arrays, chain/__init__.py:245-247): its K blocks are pulled one request at a time through its own respond() --
+        which pulls ITS inputs through the eager path -- and laid out as one batch buffer, so everything downstream
+        still runs one launch per node.  History rows come from the previous batch's tail or a fresh block request."""
+        from signals_amd.chain import BadShape, BlockLoc, Request, Shape, adopt_reply
+        N, K = self.N, self.K
+        blocks = []
+        for b in range(K):
+            loc = BlockLoc(position=self.pos + b * N, rate=self.rate, shape=Shape(frames=N, channels=channels))
+            block = adopt_reply(node.respond(Request(requestor=self.owner.requestor, port='input', loc=loc)))
+            if not (Shape.of_array(block) <= loc.shape):
+                raise BadShape(node, block.shape, loc.shape)
+            blocks.append(block)
+        widths = {int(b.shape[1]) for b in blocks}
+        if len(widths) != 1:
+            raise NotBatchable(f'{node.cls_name()} answered blocks of different widths {sorted(widths)}')
+        if all(b.shape[0] == 1 for b in blocks) and K == 1:
+            return blocks[0].to(CTRL_DTYPE)                                   # a one-row reply broadcasts, like a Fixed
+        result = torch.empty((rows, widths.pop()), dtype=AUDIO_DTYPE, device=runtime.device())
+        for b, block in enumerate(blocks):
+            result[hist + b * N: hist + (b + 1) * N] = block                  # (a one-row reply broadcasts over its block)
+        self._own_history(node, result.shape[1], hist, result)
+        return result
+
     _SCHEDULES = (
         (fixed.Fixed, _sched_fixed),
         (osc.Osc, _sched_osc),
@@ -754,6 +801,40 @@ class _VoiceChain:
         return (max(hertz.shape[1], phase.shape[1]) == v and cutoff.shape[1] == v
                 and hertz.shape[1] in (1, v) and phase.shape[1] in (1, v) and (gain is None or gain.shape[1] in (1, v)))
 
+    def cycles_per_frame_bound(self) -> tuple[float, float]:
+        """(max |hertz| / rate, max |phase|) over the chain's voices, from the host arrays behind the Fixed controls
+        (an unplugged port is 0): bounds |t| = |frame / rate * hertz + phase| of any frame without touching the device"""
+        import numpy as np
+        out = []
+        for p in (self.src.hertz, self.src.phase):
+            src = p.sig
+            if src is None or not src._state.enabled:
+                out.append(0.0)
+            else:
+                value = np.abs(np.asarray(src._state.value, dtype=np.float64))
+                out.append(float(value.max()) if value.size and np.isfinite(value).all() else float('inf'))
+        return out[0] / self.batch.rate, out[1]
+
+    def live_key(self, bus_node=None):
+        """identities of the resident control tensors (and the bus gains) as they are NOW -- `resident()` re-uploads an
+        edited array, which changes the identity; None if the pattern no longer holds.  The cheap per-block check of the
+        latency path: a bound call is reused while every identity is unchanged."""
+        for n in self.involved:
+            if not n._state.enabled:
+                return None
+        key = []
+        for p in self.ports:
+            src = p.sig
+            if src is None or not src._state.enabled:
+                key.append(None)
+            elif type(src) is fixed.Fixed:
+                key.append(src.resident())
+            else:
+                return None
+        if bus_node is not None:
+            key.append(bus_node.resident_gains())
+        return key
+
     def _same_shapes(self, now, then) -> bool:
         return now is not None and all(a.shape == b.shape for a, b in zip(now[:3], then[:3]))
 
@@ -840,11 +921,17 @@ class _VoiceChain:
             if not ready:
                 size = _native.lib().sig_fused_voice_consts_size(v) // 8
                 buf = held[2] if held is not None and held[2].numel() >= size else torch.empty(size, dtype=CTRL_DTYPE, device=dev)
-                o._steady_consts = held = (key, tuple(ctl), buf)
+                o._steady_consts = held = (key, tuple(ctl), buf, self.cycles_per_frame_bound())
+            # Past |t| = 2^26 cycles the Sine closed form (and the walker's incremental phase) hands over to the exact
+            # per-row phase, wave by wave inside the launch -- correct, but the closed-form kernel's built-in fallback is
+            # a plain loop meant for a few waves.  max |hertz| and max |phase| are host-side knowledge: when the launch's
+            # last frame puts the fastest voice past the limit, the span walker takes the whole launch instead.
+            per_frame, ph_max = held[3]
+            walk = self.kind == 'Sine' and ph_max + (position + rows) * per_frame >= _native.SINE_FAST_MAX_CYCLES
             return o._launch(bus_name, lambda: _native.fused_voice_bus(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
                                                                        ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
                                                                        workspace=o._workspace, status=status,
-                                                                       consts=held[2], consts_ready=ready),
+                                                                       consts=held[2], consts_ready=ready, walk=walk),
                              units=rows * v)
 
         def captured(position, ctl, pan_now):
@@ -870,16 +957,32 @@ class _VoiceChain:
                     return None
             return cap.run(position)
 
+        bound = [None]                                       # (live key, LatencyVoiceBusCall) of the one-launch block
+
         def replay(position: int) -> torch.Tensor:
+            if one_launch and o.timer is None:
+                # latency mode, the per-block host path: five identity checks, one allocation, one ctypes call (a hipGraph of
+                # this single launch would only add its replay cost: 19.6 us per block against 14.6)
+                key, held = self.live_key(self.bus_node), bound[0]
+                if key is not None and held is not None and len(key) == len(held[0]) and all(a is b for a, b in zip(key, held[0])):
+                    return held[1](position, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
             ctl, pan_now = self.resolve(), self.bus_node.resident_gains()
             if not self._same_shapes(ctl, controls) or (pan_now is None) != (pan is None):
                 o._replay = None
                 return o.render(position, N, K)                  # pattern no longer holds: re-plan
-            if small and o.graph_replay:
+            if small and o.graph_replay and not one_launch:
                 out = captured(position, ctl, pan_now)
                 if out is not None:
                     return out
+            if one_launch and o.timer is None:
+                key = self.live_key(self.bus_node)
+                if key is not None and (pan_now is None or pan_now.shape[1] == v) and self.widths_ok(ctl):
+                    bound[0] = (key, _native.LatencyVoiceBusCall(self.btype, rate, N, CONTEXT, v, ctl[0], ctl[1], ctl[2], ctl[3],
+                                                                 pan_now, bus_c, o._latency_ws[1], status))
             return run(position, ctl, pan_now, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
         if node is o.node:
             o._remember_replay(N, K, replay)
         return run(b.pos, controls, pan, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
+
+
+_KNOWN_TYPES = tuple(t for types, _ in _Batch._SCHEDULES for t in (types if isinstance(types, tuple) else (types,)))

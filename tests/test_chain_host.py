@@ -319,8 +319,9 @@ def test_bench_closed_form_predicate_mirrors_the_kernel():
     fast = {k: v.copy() for k, v in p.items()}
     fast['hertz'][0, 5] = 13000.0                                                      # more than a quarter turn per row
     assert not bench.steady_applies(fast, 0, 1024, 0, 1000, 256)
-    far = 2 ** 24 * 48000 // 55 + 48000                                                # 55 Hz voice past 2^24 cycles
+    far = 2 ** 26 * 48000 // 55 + 48000                                                # 55 Hz voice past 2^26 cycles
     assert not bench.steady_applies(p, 0, 1024, far * 40, far * 40 + 1000, 256)
+    assert bench.steady_applies(p, 0, 1024, 10 * 172_800_000, 10 * 172_800_000 + 1000, 256)   # ten hours in: 1760 Hz is at 2^25.9
 
 
 def test_graph_version_bumps_on_mutation():

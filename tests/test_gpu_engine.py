@@ -472,7 +472,7 @@ def test_modulated_oscillator_vs_oracle(golden):
 
 
 def test_fused_sine_fast_and_exact_phase_paths():
-    """the fused kernels advance the Sine phase incrementally while every |t| of a wave is < 2^24 cycles and use
+    """the fused kernels advance the Sine phase incrementally while every |t| of a wave is < 2^26 cycles and use
     the exact path (numpy's argument rounding tracked) beyond; both within 1e-6 of the reference arithmetic,
     including across the switch-over and at positions where float64 has ~1e-5 cycles of resolution left"""
     from oracle import chain_ref as R
@@ -485,8 +485,8 @@ def test_fused_sine_fast_and_exact_phase_paths():
     def build():
         f = fx.LowPass(); f.input = mkosc('Sine', hz, ph); f.cutoff = fix(cut)
         return f
-    switch = int(2 ** 24 / 1760 * RATE)                      # where the 1760 Hz voices cross 2^24 cycles
-    for pos in (0, HOUR, switch - 300, 10 * HOUR, 2 ** 40):
+    switch = int(2 ** 26 / 1760 * RATE)                      # where the 1760 Hz voices cross 2^26 cycles
+    for pos in (0, HOUR, 10 * HOUR, switch - 300, 40 * HOUR, 2 ** 40):
         got = batched(build(), pos, 256, 3, V, fuse=True, scan=False)
         ref = np.concatenate([R.filter_block('lp', lambda p, n: R.osc('Sine', p, n, RATE, hz, ph), pos + b * 256, 256,
                                              RATE, cut) for b in range(3)])
@@ -556,7 +556,9 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
         return bus, f.input.sig.hertz.sig
     node, hz_fixed = build(hz)
     r = BatchRenderer(node, 1, RATE, graph_replay=True)
+    r.latency_kernel = False            # (a Sine chain's one-launch block is NOT captured: a bound plain launch is faster)
     plain = BatchRenderer(build(hz)[0], 1, RATE)
+    plain.latency_kernel = False
     positions = [0, 256, 512, 768, 4096, 4352, 256]                # sequential, a seek forward, a seek back
     for pos in positions:
         a = r.render(pos, 256, 1).clone()                           # graph-owned buffer: copy before the next call
@@ -564,8 +566,15 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
     assert r._captured is not None
     hz_fixed.get_state().value = hz * 1.5                           # new array -> new upload -> re-capture
     plain2 = BatchRenderer(build(hz * 1.5)[0], 1, RATE)
+    plain2.latency_kernel = False
     for pos in (512, 768):
         assert torch.equal(r.render(pos, 256, 1).clone(), plain2.render(pos, 256, 1)), pos
+    one = BatchRenderer(build(hz)[0], 1, RATE, graph_replay=True)          # default: sig_latency_voice_bus through a bound call
+    blocks = [one.render(pos, 256, 1).clone() for pos in positions]
+    assert one._captured is None
+    ref = BatchRenderer(build(hz)[0], 1, RATE)
+    for pos, blk in zip(positions, blocks):
+        assert torch.equal(blk, ref.render(pos, 256, 1)), pos
     from signals_amd.chain.driver import BlockDriver
     d = BlockDriver(); d.input = build(hz)[0]
     e = BlockDriver(); e.input = build(hz)[0]

@@ -220,3 +220,27 @@ def test_config5_full_size_fused_equals_two_launches():
     assert outs[True].shape == (256 * 64, 4096) and bool(torch.isfinite(outs[True]).all())
     assert float((outs[True].double() - outs[False].double()).abs().max()) < 2e-6
     assert float(outs[True].abs().max()) > 0.5
+
+
+def test_bench_geometry_vs_oracle(params):
+    """the EXACT launch bench.py times -- 1024 voices, 4096 blocks of 256 frames per batch: sig_fused_voice_bus picks the
+    Sine closed form at 8 voices x 8 blocks per lane (fused_steady_bus_kernel<8, 2>, two voice tiles) -- compared with
+    the CPU oracle on whole blocks of its own output: the first four, one mid-stream, the last; then the same geometry
+    one batch further into the stream (the homogeneous state of every block comes from T_100, none from T_c0)"""
+    from signals_amd import _native
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    k = 4096
+    plan = _native.fused_voice_bus_plan('Sine', 0, V, N, k, 100)
+    assert plan == {'voices_per_lane': 8, 'blocks_per_lane': 8, 'closed_form': True, 'kernel': 'fused_steady_bus_kernel<8, C>'}
+    timer = KernelTimer()
+    r = BatchRenderer(bench.build_graph(params, 0, V), 2, RATE, timer=timer)
+    for start in (0, k * N):
+        assert bench.steady_applies(params, 0, V, start, start + k * N - 1, N)       # every wave takes the closed form
+        bus = r.render(start, N, k)
+        torch.cuda.synchronize()
+        assert set(timer.summary()) == {'fused_voice_bus[Sine,lp,gain]'}, set(timer.summary())
+        assert bus.shape == (k * N, 2)
+        per_block, scale = bench.check_batch_against_oracle(params, V, N, bus, start, k, [0, 1, 2, 3, k // 2, k - 1])
+        assert len(per_block) == 6 and scale > 1e-3
+        assert max(per_block.values()) < 1e-6 * max(1.0, scale), per_block
+        assert max(per_block.values()) < 5e-9, per_block            # in fact one float32 ulp of the 0.03 full-scale bus

@@ -1,7 +1,7 @@
 """The fused span walker (sig_fused_osc_biquad / sig_fused_voice_bus, signals_amd/csrc/fused_voice.hip) under every
 launch geometry, called through the C ABI and checked against the CPU oracle: voices per lane x blocks per lane,
 ragged voice counts, batches that are not a multiple of the span, short first contexts, block sizes at and below
-the context length, the Sine recurrence and its two fall-backs to the exact phase (positions beyond 2^24 cycles,
+the context length, the Sine recurrence and its two fall-backs to the exact phase (positions beyond 2^26 cycles,
 voices that advance more than a quarter turn per row), all four waveforms, both filter types, both sinks."""
 import os
 
@@ -122,12 +122,12 @@ def test_block_sizes_around_the_context_length(N):
 
 
 def test_sine_falls_back_to_the_exact_phase():
-    """(a) one hour into the stream a 1760 Hz voice is past 2^24 cycles; (b) voices above rate/4 advance more than
+    """(a) four hours into the stream a 6-9 kHz voice is past 2^26 cycles; (b) voices above rate/4 advance more than
     a quarter turn per row.  Both are wave-uniform fall-backs; mixed with ordinary voices in other waves."""
     V, N, K = 192, 256, 4
     p = params(V, 6)
-    p['hertz'][0, :64] = np.random.default_rng(7).uniform(6000, 9000, 64)           # wave 0 (at vpt=1): large t at 1 h
-    hour = 172_800_000
+    p['hertz'][0, :64] = np.random.default_rng(7).uniform(6000, 9000, 64)           # wave 0 (at vpt=1): large t at 4 h
+    hour = 4 * 172_800_000
     ref = oracle_chain('Sine', 'lp', p, hour, N, K)
     for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 4)]:
         geometry(vpt, span)
@@ -203,7 +203,7 @@ def test_closed_form_sine_kernel_matches_the_walker_and_the_oracle(btype, pos):
 
 
 def test_closed_form_kernel_leaves_unqualified_waves_to_the_walker():
-    """per-wave choice: voices below ~8 Hz (sin(theta) < 1e-3), above rate/4, or past 2^24 cycles keep their whole
+    """per-wave choice: voices below ~8 Hz (sin(theta) < 1e-3), above rate/4, or past 2^26 cycles keep their whole
     wave on the walker; the bus is the sum of both kernels' partial tiles"""
     V, N, K = 256, 256, 6
     p = params(V, 30)

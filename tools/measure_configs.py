@@ -17,38 +17,21 @@ import torch
 RATE = 48000
 
 
-def fixed(v):
-    from signals_amd.chain.fixed import Fixed
-    f = Fixed()
-    f.get_state().value = np.ascontiguousarray(np.array(v, ndmin=2, dtype=float))
-    return f
+import bench_configs as cfg
 
 
 def c3(V):
     """Saw -> LowPass -> LowPass -> (x ADSR) -> SumBus, N = 1024"""
-    from signals_amd.chain import ext, fx, osc
-    rng = np.random.default_rng(0)
-    o = osc.Sawtooth(); o.hertz = fixed(rng.uniform(55, 1760, (1, V))); o.phase = fixed(rng.uniform(0, 1, (1, V)))
-    f1 = fx.LowPass(); f1.input = o; f1.cutoff = fixed(rng.uniform(200, 8000, (1, V)))
-    f2 = fx.LowPass(); f2.input = f1; f2.cutoff = fixed(rng.uniform(200, 8000, (1, V)))
-    env = ext.ADSR()
-    for name, (lo, hi) in dict(attack=(0.001, 0.05), decay=(0.01, 0.2), sustain=(0.2, 0.9), release=(0.05, 0.5),
-                               gate_on=(0.0, 0.5), gate_off=(1.0, 4.0)).items():
-        setattr(env, name, fixed(rng.uniform(lo, hi, (1, V))))
-    rm = fx.RingMod(); rm.left = f2; rm.right = env
-    bus = ext.SumBus(); bus.input = rm
-    return bus, 1, 1024, 256, {'osc_bank': 4, 'biquad_coldstart': 8, 'adsr': 4, 'adsr_apply': 8, 'fused_osc_biquad': 4, 'elementwise': 12, 'sum_bus': 4, 'biquad_bus': 4}
+    return cfg.c3_graph(cfg.c3_params(V)), 1, 1024, 256, ALGO
 
 
 def c5(V):
     """Sine -> LowPass -> MixMatrix(64x64), V = 4096, N = 256"""
-    from signals_amd.chain import ext, fx, osc
-    rng = np.random.default_rng(0)
-    o = osc.Sine(); o.hertz = fixed(rng.uniform(55, 1760, (1, V))); o.phase = fixed(rng.uniform(0, 1, (1, V)))
-    f = fx.LowPass(); f.input = o; f.cutoff = fixed(rng.uniform(200, 8000, (1, V)))
-    mm = ext.MixMatrix(); mm.input = f
-    mm.get_state().matrix = np.linalg.qr(rng.standard_normal((64, 64)))[0]
-    return mm, V, 256, 64, {'fused_osc_biquad': 4, 'mix_matrix': 8, 'osc_bank': 4, 'biquad_coldstart': 8, 'fused_osc_biquad_mix': 4}
+    return cfg.c5_graph(cfg.c5_params(V)), V, 256, 64, ALGO
+
+
+ALGO = {'osc_bank': 4, 'biquad_coldstart': 8, 'adsr': 4, 'adsr_apply': 8, 'fused_osc_biquad': 4, 'elementwise': 12, 'sum_bus': 4,
+        'biquad_bus': 4, 'mix_matrix': 8, 'fused_osc_biquad_mix': 4}
 
 
 def run(name, build, V, steps=10):
