@@ -67,20 +67,56 @@ def steady_applies(p, lo, hi, first_frame, last_frame, N, ctx=100):
                 and (N >= ctx or first_frame >= ctx))
 
 
-def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2, steady=False):
+def closed_form_live_fraction(p, lo, hi, N, vpt, ctx=100, bus_channels=2, tol=1e-11):
+    """Host mirror of what fused_steady_bus_kernel does with the bench's voices: the fraction of (voice slot, row) pairs
+    whose homogeneous part is still carried.  Mirrors steady_prep_kernel's decay bound (rows from the cold start until
+    the homogeneous part is below `tol` of the voice's full scale), the engine's voice order (engine.py:
+    ordered_by_cutoff: groups of 64 neighbours in cutoff dealt round robin over the voice tiles, slot-major), the
+    wave-maximum per slot and the kernel's row-group variants."""
+    hz, cut = p['hertz'][0, lo:hi], p['cutoff'][0, lo:hi]
+    k = np.tan(np.pi * (cut / (RATE / 2)) / 2); k2 = k * k; nrm = 1 / (1 + np.sqrt(2) * k + k2)
+    b0, a1, a2 = k2 * nrm, 2 * (k2 - 1) * nrm, (1 - np.sqrt(2) * k + k2) * nrm
+    d = hz / RATE; z = np.exp(-2j * np.pi * (d - np.rint(d)))
+    H = (1 + 2 * z + z * z) / (1 + a1 * z + a2 * z * z)
+    P = H - 1; Q = P / z - 2 + a1 * H
+    d2 = a2 - 0.25 * a1 * a1; f2 = 1 + 0.25 * a1 * a1 + d2
+    kappa = (f2 + np.sqrt(np.maximum(f2 * f2 - 4 * d2, 0))) / (2 * np.sqrt(d2))
+    amp = b0 * kappa * np.sqrt(np.abs(P) ** 2 + np.abs(Q) ** 2)
+    nd = np.where(amp > tol, np.ceil(np.log(tol / amp) / (0.5 * np.log(a2))) + 1, 0.0)
+    v, tile = hi - lo, 64 * vpt
+    if v % tile:
+        return 1.0
+    order = np.argsort(cut, kind='stable'); tiles = v // tile
+    q = np.arange(v); group, lane = q // 64, q % 64
+    perm = np.empty(v, dtype=np.int64)
+    perm[((group % tiles) * 64 + lane) * vpt + group // tiles] = order[q]
+    drop = np.maximum(nd[perm].reshape(tiles, 64, vpt).max(axis=1) - ctx, 0)          # (tile, slot): first row without it
+    variants = {16: (16, 12, 8, 6, 4, 3, 2, 1, 0), 8: (8, 6, 4, 3, 2, 1, 0), 4: (4, 2, 1, 0), 2: (2, 1, 0), 1: (1, 0)}[vpt]
+    R = 16 // bus_channels
+    live = 0
+    for t in range(tiles):
+        for r0 in range(0, N - N % R, R):
+            m = max([i + 1 for i in range(vpt) if drop[t, i] > r0], default=0)
+            live += R * min(x for x in variants if x >= m)
+        live += (N % R) * vpt
+    return live / (tiles * N * vpt)
+
+
+def fused_f64_ops_per_voice_sample(name, voices, N, K, ctx=100, bus_channels=2, steady=False, live_fraction=1.0):
     """f64-rate VALU instructions per stored voice-sample of the fused Sine kernels, counted in the ISA.
     Walker: 2 for the oscillator recurrence on every row a lane walks (span*N + c rows per span*N stored), 4 for
-    the b0-normalised DF2T on (N + c)/N rows (every block is warmed up c rows).  Closed form (`steady`): 2 for the
-    steady-state recurrence, 2 for the homogeneous one, 1 to add them, no warm-up rows.  Then per stored row either
-    C bus FMAs + C/vpt adds of the cross-lane flush (16 adds per lane per 16/C rows), or 1 multiply + 1 conversion
-    for the f32 store."""
+    the b0-normalised DF2T on (N + c)/N rows (every block is warmed up c rows), then per stored row either C bus FMAs +
+    C/vpt adds of the cross-lane flush (16 adds per lane per 16/C rows), or 1 multiply + 1 conversion for the f32 store.
+    Closed form (`steady`): 1 for the steady-state two-term recurrence, C bus FMAs, 17 adds per lane per 16/C rows of the
+    folded cross-lane sum, and 3 (homogeneous recurrence + sum) on the `live_fraction` of (voice slot, row) pairs whose
+    homogeneous part has not decayed yet; no warm-up rows."""
     from signals_amd import _native
     vpt, span = _native.fused_geometry(voices, N, K, ctx)
     sink = bus_channels + bus_channels / vpt if name == 'fused_voice_bus' else 2.0
     if steady and name == 'fused_voice_bus':
         plan = _native.fused_voice_bus_plan('Sine', ctx, voices, N, K, ctx)
         vpt, span = plan['voices_per_lane'], plan['blocks_per_lane']
-        return 5.0 + bus_channels + bus_channels / vpt, vpt, span
+        return 1.0 + bus_channels + 3.0 * live_fraction + 17.0 * bus_channels / (16 * vpt), vpt, span
     return 2.0 * (span * N + ctx) / (span * N) + 4.0 * (N + ctx) / N + sink, vpt, span
 
 
@@ -104,6 +140,12 @@ def hbm_roofline(kernels: dict, dom: str, traffic) -> dict:
             'algo_bytes_per_voice_sample': k['algo_bytes_per_voice_sample'], 'avg_launch_ms': k['avg_ms']}
 
 
+def _with_practical(detail: dict, achieved: float) -> dict:
+    if isinstance(detail.get('practical_peak'), dict):
+        detail = dict(detail, practical_peak=dict(detail['practical_peak'], frac=achieved / detail['practical_peak']['value']))
+    return detail
+
+
 def valu_roofline(kernels: dict, dom: str, units_per_call: float, ops: float, traffic, detail: dict) -> dict:
     """a fused voice kernel: f64 VALU instruction-lanes per second against the chip's f64 vector issue peak; the HBM
     view of the same launch (it moves almost nothing) is nested under `hbm`"""
@@ -111,7 +153,7 @@ def valu_roofline(kernels: dict, dom: str, units_per_call: float, ops: float, tr
     ach = ops * units_per_call / (k['avg_ms'] * 1e-3) / 1e12
     return {'bound': 'valu_f64', 'kernel': dom, 'achieved': ach, 'peak': F64_VALU_PEAK, 'unit': 'T f64-instr-lanes/s',
             'frac': ach / F64_VALU_PEAK, 'traffic': traffic, 'f64_ops_per_voice_sample': ops,
-            'avg_launch_ms': k['avg_ms'], **detail,
+            'avg_launch_ms': k['avg_ms'], **_with_practical(detail, ach),
             'hbm': {'achieved': k['algo_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k['algo_GBs'] / HBM_PEAK_GBS,
                     'algo_bytes_per_voice_sample': k['algo_bytes_per_voice_sample'],
                     'note': 'SURVEY.md 8d: the fused lower bound is ~16/V B per voice-sample, so this launch is f64-VALU-bound '
@@ -390,10 +432,16 @@ def main():
             dom = max(summ, key=lambda k: summ[k]['ms'])
             fam = dom.split('[')[0]
             if fam in VALU_BOUND:
-                ops, vpt, span = fused_f64_ops_per_voice_sample(fam, V, N, K, steady=closed)
                 plan = _native.fused_voice_bus_plan('Sine', args.position + N * K, V, N, K, 100)
+                live = closed_form_live_fraction(params, rank * V, (rank + 1) * V, N, plan['voices_per_lane']) if closed else 1.0
+                ops, vpt, span = fused_f64_ops_per_voice_sample(fam, V, N, K, steady=closed, live_fraction=live)
                 res['roofline'] = valu_roofline(kernels, dom, summ[dom]['units'] / summ[dom]['calls'], ops, pmc_traffic(fam), {
                     'voices_per_lane': vpt, 'blocks_per_lane': span, 'device_kernel': plan['kernel'].replace('C>', '2>'),
+                    'homogeneous_live_fraction': live,
+                    'practical_peak': {'value': 30.8, 'frac': None,
+                                       'note': 'tools/ubench/f64_rates.hip: back-to-back independent v_fma_f64 reach 5.1 cycles per '
+                                               'wave-instruction counted at 2.4 GHz (the chip holds ~1.9 GHz under f64 load), i.e. '
+                                               '30.8 T instr-lanes/s is what this instruction mix can reach at all'},
                     'path': 'closed form: steady-state sinusoid + homogeneous transient per block, no warm-up rows '
                             '(fused_steady_bus_kernel); only constant-parameter Sine->LowPass|HighPass->[Gain]->SumBus takes it: '
                             'other oscillators run the span walker (~2.0 T voice-samples/s), interposed effects or modulated '

@@ -398,14 +398,22 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // zero, fx.py:104's sosfilt start).  Every ingredient is linear in (yss_n, yss_{n+1} - yss_n), so the homogeneous
 // state at a block's first row p = r0 + c is one per-voice 2x2 matrix applied to the steady-state oscillator's
 // state at p:   (z0h, z1h)_{p-1} = T_c (yss_p, dss_p),   T_c = -A^c Mss(c)   -- no warm-up rows at all.
-// Per stored sample: 2 (yss recurrence, difference form) + 2 (homogeneous recurrence) + 1 (sum) + C (bus) f64
-// ops instead of 2 (N+c')/N + 4 (N+c)/N + C.  Mathematically identical to the walker; rounding differs at 1e-14.
-// A wave takes this path when every voice of it passes steady_voice_ok(); the rare other waves run
+// Per stored sample: 1 (yss: the two-term recurrence y_{n+1} = 2 cos(theta) y_n - y_{n-1}, one fma, re-seeded from the
+// reference's own t at every span start; its error grows like rows * 2e-16 / sin(theta), < 1e-9 for the voices this
+// kernel accepts) + C (bus) + C/VPT (flush), and -- only while the homogeneous part of a voice is still above 1e-11
+// of that voice's full scale -- 2 (homogeneous recurrence) + 1 (sum).  The homogeneous part decays like the pole
+// radius^n and has already decayed over the c warm-up rows when the block starts: steady_prep_kernel bounds it
+// rigorously per voice (rows from the cold start until it is below the tolerance, SC_ND), the kernel takes the wave
+// maximum per voice SLOT (the i-th voice of every lane) and runs row groups in variants with only the first M slots
+// "live".  A caller that orders its voices so that a slot holds neighbours in cutoff (the engine sorts by cutoff,
+// slot-major) gets most row groups at M = 0; any order is correct.  Mathematically identical to the walker; rounding
+// differs at 1e-10.  A wave takes this path when every voice of it passes steady_voice_ok(); the rare other waves run
 // steady_fallback_span inside the same launch.
 // Per-voice constants, computed once per launch by steady_prep_kernel into the tail of the workspace (SoA, kSteadyConsts
-// rows of `voices` doubles): the filter, the oscillator step, H(e^{j theta}) and T_c for c = ctx and for the
-// launch's first block (c = min(ctx, position)).
-enum { SC_NA1, SC_NA2, SC_SCALE, SC_NM, SC_ST, SC_GR, SC_HRE, SC_HIM, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
+// rows of `voices` doubles): the filter, the oscillator step, H(e^{j theta}), T_c for c = ctx and for the launch's first
+// block (c = min(ctx, position)), and the decay bound.
+enum { SC_NA1, SC_NA2, SC_SCALE, SC_K2C, SC_ST, SC_CT, SC_HRE, SC_HIM, SC_ND, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
+constexpr double kHomogeneousTol = 1e-11;     // of one voice's full scale (unit-amplitude oscillator, before gain and pan)
 
 // per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^26 cycles over
 // the span (as for the walker's Sine recurrence), at most a quarter turn per row, and sin(theta) not tiny (the map
@@ -468,10 +476,26 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
     const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
     const M2 T0 = (c0 == a.ctx) ? T : make_T(c0);
     auto put = [&](int k, double x) { consts[(int64_t)k * a.voices + v] = x; };
+    // Rows after a cold start until the homogeneous part is below kHomogeneousTol of the voice's full scale, for good:
+    // in the coordinates S x in which A is a rotation times the pole radius rho = sqrt(a2) the state shrinks by exactly
+    // rho per row, so |yh_n| <= cond(S) rho^n |x_0| with x_0 = minus the steady-state DF2T state, |x_0| <= sqrt(|P|^2 + |Q|^2)
+    // (b0-normalised, hence the factor b0).  S^-1 = [[1, 0], [a1/2, d]], d = sqrt(a2 - a1^2/4) (eigenvector (1, a1 + lambda));
+    // its condition number from the Frobenius norm and the determinant.  NaN or real poles: never (infinity).
+    double nd = __builtin_inf();
+    {
+        const double d2 = a2 - 0.25 * a1 * a1;
+        if (ok && d2 > 0.0 && a2 > 0.0 && a2 < 1.0) {
+            const double d = sqrt(d2), f2 = 1.0 + 0.25 * a1 * a1 + d2;
+            const double kappa = (f2 + sqrt(fmax(f2 * f2 - 4.0 * d2, 0.0))) / (2.0 * d);
+            const double amp = q.b0 * kappa * sqrt(P.re * P.re + P.im * P.im + Q.re * Q.re + Q.im * Q.im);
+            const double rows = (amp > kHomogeneousTol) ? log(kHomogeneousTol / amp) / (0.5 * log(a2)) : 0.0;
+            if (rows == rows) nd = ceil(rows) + 1.0;
+        }
+    }
     put(SC_NA1, -a1); put(SC_NA2, -a2);
     put(SC_SCALE, GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0);
-    put(SC_NM, -4.0 * sh * sh); put(SC_ST, st); put(SC_GR, -2.0 * sh * sh);
-    put(SC_HRE, H.re); put(SC_HIM, H.im);
+    put(SC_K2C, 2.0 * ct); put(SC_ST, st); put(SC_CT, ct);
+    put(SC_HRE, H.re); put(SC_HIM, H.im); put(SC_ND, nd);
     put(SC_T + 0, T.a); put(SC_T + 1, T.b); put(SC_T + 2, T.c); put(SC_T + 3, T.d);
     put(SC_T0 + 0, T0.a); put(SC_T0 + 1, T0.b); put(SC_T0 + 2, T0.c); put(SC_T0 + 3, T0.d);
 }
@@ -529,14 +553,54 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
     if (stage.staged) stage.now();
 }
 
+// wave-wide maximum of a non-negative int, the same value in every lane
+__device__ __forceinline__ int wave_max_int(int x) {
+#pragma unroll
+    for (int d = 1; d < SIG_WAVE; d <<= 1) {
+        const int y = __shfl_xor(x, d, SIG_WAVE);
+        x = (y > x) ? y : x;
+    }
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+constexpr int kNeverDrops = 0x3fffffff;
+
+// the row-group variants of fused_steady_bus_kernel: "the first M of the lane's VPT voice slots still carry their
+// homogeneous part", largest first
+template <int VPT> struct SteadyVariants {
+    static constexpr int count = (VPT == 16) ? 9 : (VPT == 8) ? 7 : (VPT == 4) ? 4 : (VPT == 2) ? 3 : 2;
+    static constexpr int at(int k) {
+        constexpr int v16[9] = {16, 12, 8, 6, 4, 3, 2, 1, 0}, v8[7] = {8, 6, 4, 3, 2, 1, 0}, v4[4] = {4, 2, 1, 0},
+                      v2[3] = {2, 1, 0}, v1[2] = {1, 0};
+        return (VPT == 16) ? v16[k] : (VPT == 8) ? v8[k] : (VPT == 4) ? v4[k] : (VPT == 2) ? v2[k] : v1[k];
+    }
+};
+
+// Register budget of the closed-form kernel, as waves per SIMD the compiler must leave room for: its row groups are
+// straight-line code with many independent chains, which the scheduler otherwise spreads over every register it can
+// get (8 voices per lane: 417 registers and scratch, for 210 live values).
+#ifndef SIG_STEADY_OCC8
+#define SIG_STEADY_OCC8 1
+#endif
+#ifndef SIG_STEADY_AUTO16
+#define SIG_STEADY_AUTO16 0              // 16 voices per lane spill (512 registers + scratch): tuning hook only
+#endif
+#ifndef SIG_STEADY_OCC16
+#define SIG_STEADY_OCC16 1
+#endif
+template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ? SIG_STEADY_OCC16 : (VPT == 8) ? SIG_STEADY_OCC8 : 2; };
+
 template <int VPT, int C>
-__global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
+void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     constexpr int R = kPairs / C;          // rows per flush
+    static_assert(R % 2 == 0, "the two-term recurrence rotates two registers per voice: row groups are even");
     __shared__ double lds[4][kPairs * kTileStride];
     const int lane = threadIdx.x & 63;
-    double* tile = lds[threadIdx.x >> 6];
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
+    double* tile = lds[wave];                                                  // everything derived from it lives in SGPRs and branches are scalar
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
     if (b_first >= a.K) return;                                               // wave-uniform
@@ -550,14 +614,18 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
     }
     const double* sc = a.steady_consts;
 
-    double na1[VPT], na2[VPT], nm[VPT], yss[VPT], dss[VPT], wt[C][VPT];
+    // per voice: the filter (na1, na2), the oscillator step k = 2 cos(theta), the steady-state output at rows p0 - 1
+    // and p0 (ya, yb), the bus weights; per voice SLOT (wave-uniform): rows from a cold start after which the
+    // homogeneous part is dropped
+    double na1[VPT], na2[VPT], k2c[VPT], ya[VPT], yb[VPT], wt[C][VPT];
+    int nd_total[VPT];
     const double q_first = (double)p0 / a.rate;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const bool live = v0 + i < a.voices;
         const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
         auto cst = [&](int k) { return sc[(int64_t)k * a.voices + v]; };
-        na1[i] = cst(SC_NA1); na2[i] = cst(SC_NA2); nm[i] = cst(SC_NM);
+        na1[i] = cst(SC_NA1); na2[i] = cst(SC_NA2); k2c[i] = cst(SC_K2C);
         // the design is checked where the constants are made (steady_prep_kernel); a caller that keeps them across
         // calls skips that launch, so every launch that USES a rejected design (NaN coefficients) reports it again
         if (live && na1[i] != na1[i] && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
@@ -565,71 +633,175 @@ __global__ __launch_bounds__(256) void fused_steady_bus_kernel(FusedArgs a, BusA
 #pragma unroll
         for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0 on the bus
             wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0;
-        // steady-state oscillator at the span's first row: w = H e^{j phi}, yss = Im w, dss = Im(w (e^{j theta} - 1))
+        // steady-state oscillator at the span's first row: w = H e^{j phi}, yss_p0 = Im w, yss_{p0-1} = Im(w e^{-j theta})
         const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
         const double t_first = q_first * hz + ph;                              // osc.py:32
         const double f0 = t_first - rint(t_first);                             // exact, |f0| <= 0.5
         const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
         const double hre = cst(SC_HRE), him = cst(SC_HIM);
         const double wr = fma(hre, ur, -(him * ui)), wi = fma(hre, ui, him * ur);
-        yss[i] = wi;
-        dss[i] = fma(wr, cst(SC_ST), wi * cst(SC_GR));
+        yb[i] = wi;
+        ya[i] = fma(wi, cst(SC_CT), -(wr * cst(SC_ST)));
+        const double nd = cst(SC_ND);
+        const int mine = (live && nd < (double)kNeverDrops) ? (int)nd : (live ? kNeverDrops : 0);   // NaN: never
+        nd_total[i] = wave_max_int(mine);
     }
 
     double* dstp = bus.partials + (int64_t)vt * bus.rows * C;                  // [tile][row][c]
     sig_bus::PipelinedTile<C> stage(tile, lane, dstp, b_first * a.N);
 
     double z0h[VPT], z1h[VPT];
-    auto row = [&](double* where) {                                            // one row of every voice into the tile
+    // One row of every voice; the first M slots carry their homogeneous part, the others have dropped it.  The row's C
+    // sums over the lane's voices go to `sums` (registers of the group being built, or the LDS slot of the single-row
+    // form).  The two-term recurrence runs IN PLACE on two registers per voice: on an even row yb is the sample and ya
+    // becomes the one after next, on an odd row the roles are swapped -- no register rotation for the compiler to undo.
+    auto row = [&](double* sums, int sums_stride, auto m_tag, auto odd_tag) {
+        constexpr int M = decltype(m_tag)::value;
+        constexpr bool ODD = decltype(odd_tag)::value;
         double y[VPT];
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            y[i] = yss[i] + z0h[i];
-            const double yh = z0h[i];
-            z0h[i] = fma(na1[i], yh, z1h[i]);
-            z1h[i] = na2[i] * yh;
-            yss[i] += dss[i];
-            dss[i] = fma(nm[i], yss[i], dss[i]);
+            const double ys = ODD ? ya[i] : yb[i];
+            if (ODD) yb[i] = fma(k2c[i], ya[i], -yb[i]);
+            else ya[i] = fma(k2c[i], yb[i], -ya[i]);
+            if (i < M) {
+                y[i] = ys + z0h[i];
+                const double yh = z0h[i];
+                z0h[i] = fma(na1[i], yh, z1h[i]);
+                z1h[i] = na2[i] * yh;
+            } else {
+                y[i] = ys;
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < VPT; ++i) acc = fma(wt[ch][i], y[i], acc);
-            where[ch * kTileStride] = acc;
+            sums[ch * sums_stride] = acc;
         }
     };
+    // One group of R rows: their kPairs sums stay in registers, are folded across lanes (sig_bus::FoldedGroup) and the
+    // LDS reads of the last step are issued at once; they are consumed half-way through the NEXT group, when they (and
+    // the stores in front of them: a wave's LDS operations complete in order) have long retired.
+    sig_bus::FoldedGroup<C> folded(tile, lane, dstp);
+    double pend[4];
+    int64_t pend_row = 0;
+    bool have = false;
+    // Two consecutive rows at once (an even one and an odd one, see `row`), so that their 2 C bus sums are FOUR
+    // independent accumulation chains: a lone wave issues an f64 instruction every 4 cycles but a dependent one only
+    // every ~10, and two interleaved chains (one row's two channels) ran at 60 % of the issue rate.
+    auto rows2 = [&](double* sums, auto m_tag) {
+        constexpr int M = decltype(m_tag)::value;
+        double y0[VPT], y1[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            y0[i] = yb[i];
+            ya[i] = fma(k2c[i], yb[i], -ya[i]);
+            y1[i] = ya[i];
+            yb[i] = fma(k2c[i], ya[i], -yb[i]);
+            if (i < M) {
+                const double h0 = z0h[i];
+                y0[i] += h0;
+                const double h1 = fma(na1[i], h0, z1h[i]);
+                y1[i] += h1;
+                z0h[i] = fma(na1[i], h1, na2[i] * h0);
+                z1h[i] = na2[i] * h1;
+            }
+        }
+        double acc0[C], acc1[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) { acc0[ch] = 0.0; acc1[ch] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                acc0[ch] = fma(wt[ch][i], y0[i], acc0[ch]);
+                acc1[ch] = fma(wt[ch][i], y1[i], acc1[ch]);
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) { sums[ch] = acc0[ch]; sums[C + ch] = acc1[ch]; }
+    };
+    auto group = [&](auto m_tag) {
+        double acc[kPairs];
+#pragma unroll
+        for (int k = 0; k < R; k += 2) {
+            rows2(acc + k * C, m_tag);
+#pragma unroll
+            for (int q = 0; q < kPairs / 4; ++q)                               // every four sums are folded as soon as they exist
+                if (4 * q + 3 < (k + 2) * C && 4 * q + 3 >= k * C)
+                    folded.fold4(q, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if (k + 2 == R / 2 && have) folded.finish(pend, pend_row, R);
+        }
+        folded.issue(pend);
+        pend_row = stage.first; stage.first += R; have = true;
+    };
+    // Row groups come in variants "the first M slots live", M from kVariants; within a block the number of live slots only
+    // falls, so a block is a sequence of PHASES, one plain loop per variant (a switch per group cost 20-30 %: the
+    // variants' registers had to be shuffled into one layout at every merge).  Phase of variant M runs until every slot
+    // >= the next smaller variant has dropped.
+    using Variants = SteadyVariants<VPT>;
+    const int n_groups = (a.N / R) * R;                                        // rows of a block done in whole groups
 
     for (int bi = 0; bi < nb; ++bi) {
         // homogeneous state at the block's first row; only the launch's very first block can have a short context
-        const int tk = (b_first + bi == 0) ? SC_T0 : SC_T;
+        const bool first = (b_first + bi == 0);
+        const int tk = first ? SC_T0 : SC_T;
+        const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
+        int drop_at[VPT];                                                      // row of the block from which slot i is dropped
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int v = (v0 + i < a.voices) ? v0 + i : vc;
-            const double* t = sc + (int64_t)tk * a.voices + v;
-            z0h[i] = fma(t[0], yss[i], t[a.voices] * dss[i]);
-            z1h[i] = fma(t[2 * (int64_t)a.voices], yss[i], t[3 * (int64_t)a.voices] * dss[i]);
+            drop_at[i] = (nd_total[i] > c) ? nd_total[i] - c : 0;              // wave-uniform
+            if (drop_at[i] > 0) {
+                const int v = (v0 + i < a.voices) ? v0 + i : vc;
+                const double* t = sc + (int64_t)tk * a.voices + v;
+                const double dss = fma(k2c[i], yb[i], -ya[i]) - yb[i];          // yss_{p+1} - yss_p
+                z0h[i] = fma(t[0], yb[i], t[a.voices] * dss);
+                z1h[i] = fma(t[2 * (int64_t)a.voices], yb[i], t[3 * (int64_t)a.voices] * dss);
+            } else {
+                z0h[i] = 0.0; z1h[i] = 0.0;
+            }
         }
         int done = 0;
-        auto single = [&]() {
-            row(stage.slot);
+        auto single = [&]() {                                                  // (dropped slots carry zeros: the full row is exact)
+            row(stage.slot, kTileStride, std::integral_constant<int, VPT>{}, std::false_type{});
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) { const double t = ya[i]; ya[i] = yb[i]; yb[i] = t; }   // back to (previous, current)
             ++done;
             stage.advance();
         };
+        const bool ragged = stage.staged != 0;                                 // (the previous block left a partly filled tile)
         while (stage.staged != 0 && done < a.N) single();
-        double pend[16];
-        int64_t pend_row = 0;
-        bool have = false;
-        for (; done + R <= a.N; done += R) {
+        // phases; after single rows `done` is not a multiple of R, the groups simply start there
+        const int last_group_row = done + ((a.N - done) / R) * R;
+        auto phase = [&](auto k_tag) {
+            constexpr int K = decltype(k_tag)::value;
+            constexpr int M = Variants::at(K);
+            constexpr int lower = (K + 1 < Variants::count) ? Variants::at(K + 1) : 0;
+            int until = 0;                                                     // first row at which every slot >= lower has dropped
 #pragma unroll
-            for (int k = 0; k < R; ++k) row(stage.at(k));
-            if (have) stage.finish(pend, pend_row, R);
-            stage.issue(pend);
-            pend_row = stage.first; stage.first += R; have = true;
+            for (int i = lower; i < VPT; ++i) until = (i < M && drop_at[i] > until) ? drop_at[i] : until;
+            if (M == 0) until = a.N;
+            until = (until < last_group_row) ? until : last_group_row;
+            while (done < until) {                                             // (a group that starts before `until` runs whole)
+                group(std::integral_constant<int, M>{});
+                done += R;
+            }
+        };
+#define SIG_PHASE(K) if constexpr (K < Variants::count) phase(std::integral_constant<int, K>{});
+        SIG_PHASE(0) SIG_PHASE(1) SIG_PHASE(2) SIG_PHASE(3) SIG_PHASE(4) SIG_PHASE(5) SIG_PHASE(6) SIG_PHASE(7) SIG_PHASE(8)
+#undef SIG_PHASE
+        if (done < a.N) {                                                      // rows left over: one at a time, after the pending flush
+            if (have) { folded.finish(pend, pend_row, R); have = false; }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i)
+                if (drop_at[i] <= done) { z0h[i] = 0.0; z1h[i] = 0.0; }        // dropped slots were not advanced: exact zeros
+            while (done < a.N) single();
         }
-        if (have) stage.finish(pend, pend_row, R);
-        while (done < a.N) single();
+        (void)ragged; (void)n_groups;
     }
+    if (have) folded.finish(pend, pend_row, R);
     if (stage.staged) stage.now();
 }
 
@@ -702,9 +874,20 @@ BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
         if (p.steady) {
             // the closed form needs few registers per voice: 8 voices per lane (one wave per SIMD, 302 registers) beat
             // 4 (two waves) by 5 % when the launch still has a wave for every SIMD -- half the flushes per sample
+            // Better still 16 (the cross-lane flush -- 16 LDS stores and 16 loads per lane per 8 rows, the kernel's real
+            // bottleneck: 13 + 8 cycles of the CU's LDS path per pair, shared by four SIMDs -- is paid per LANE and row,
+            // so its cost per voice-sample halves), with shorter spans if that is what keeps a wave on every SIMD.
             const int env_vpt = tuning().vpt;                                  // tuning / test hook
-            const int64_t waves8 = (int64_t)((a.voices + SIG_WAVE * 8 - 1) / (SIG_WAVE * 8)) * ((a.K + p.span - 1) / p.span);
-            if (env_vpt == 8 || (env_vpt == 0 && p.vpt == 4 && waves8 >= kWavesWanted / 2)) p.vpt = 8;
+            auto waves = [&](int v, int s) { return (int64_t)((a.voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((a.K + s - 1) / s); };
+            if (env_vpt == 8 || (env_vpt == 0 && p.vpt == 4 && waves(8, p.span) >= kWavesWanted / 2)) p.vpt = 8;
+            if (env_vpt == 16 || (SIG_STEADY_AUTO16 && env_vpt == 0 && p.vpt == 8 && a.voices >= SIG_WAVE * 16)) {
+                int span = p.span;
+                while (span > 1 && waves(16, span) < kWavesWanted / 2) span >>= 1;
+                if (env_vpt == 16 || waves(16, span) >= kWavesWanted / 2) {
+                    p.vpt = 16;
+                    if (tuning().span == 0) p.span = span;
+                }
+            }
         }
     }
     return p;
@@ -730,6 +913,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
             case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             case 8: fused_steady_bus_kernel<8, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 16: fused_steady_bus_kernel<16, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
         }
         const int e2 = sig_launch_status();

@@ -14,6 +14,16 @@ constexpr int kPairs = 16;                 // (row, channel) pairs reduced per f
 constexpr int kTileStride = 65;            // doubles
 constexpr int kTileDoubles = kPairs * kTileStride;
 
+// The 16 lane-group partials of one (row, channel) pair added pairwise (depth 4), in this fixed order: a serial chain of 16
+// dependent f64 adds costs a lone wave ~150 cycles per flush (measured: the closed-form bus kernel spent a quarter of
+// its time there), the tree a quarter of that, and its independent adds interleave with the next rows' arithmetic.
+__device__ __forceinline__ double sum16(const double (&pv)[16]) {
+    const double a0 = pv[0] + pv[1], a1 = pv[2] + pv[3], a2 = pv[4] + pv[5], a3 = pv[6] + pv[7];
+    const double a4 = pv[8] + pv[9], a5 = pv[10] + pv[11], a6 = pv[12] + pv[13], a7 = pv[14] + pv[15];
+    const double b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7;
+    return (b0 + b1) + (b2 + b3);
+}
+
 // the simple form (HBM-bound callers; the f64-issue-bound fused kernels keep their own software-pipelined variant):
 // row k of a group of R = kPairs/C consecutive rows goes to tile row k (k is a compile-time constant in an unrolled
 // loop), then one flush per group stores the rows of it that are wanted
@@ -34,10 +44,10 @@ struct Tile {
     // for partials that another workgroup of the SAME launch reads after an arrival counter (no L2 write-back fence)
     template <bool AGENT = false>
     __device__ __forceinline__ void flush(int64_t out_row0, int k_lo, int k_hi) {
-        double s = 0.0;
+        double pv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += col[k];
-        s = sig_sum_rows_f64(s);
+        for (int k = 0; k < 16; ++k) pv[k] = col[k];
+        const double s = sig_sum_rows_f64(sum16(pv));
         const int k = lane / C;
         if (lane < kPairs && k >= k_lo && k < k_hi) {
             if (AGENT) __hip_atomic_store(dstp + (out_row0 + k) * C + lane % C, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -66,10 +76,7 @@ struct PipelinedTile {
         for (int k = 0; k < 16; ++k) pv[k] = col[k];
     }
     __device__ __forceinline__ void finish(const double (&pv)[16], int64_t row0, int nrows) const {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += pv[k];
-        s = sig_sum_rows_f64(s);
+        const double s = sig_sum_rows_f64(sum16(pv));
         if (lane < nrows * C) dstp[row0 * C + lane] = s;
     }
     __device__ __forceinline__ void now() {                                    // flush what is staged, at once
@@ -84,6 +91,38 @@ struct PipelinedTile {
     __device__ __forceinline__ void advance() {                                // single-row mode: one row was written at `slot`
         slot += C * kTileStride;
         if (++staged == R) now();
+    }
+};
+
+// The folded form, for kernels that produce a group's kPairs (row, channel) sums in registers (the closed-form bus
+// kernel, whose only real cost besides its recurrences was this reduction: 16 LDS stores + 16 loads per lane per group
+// take 13 + 8 cycles of the CU's LDS path each, shared by four SIMDs).  The sums are taken four at a time, in the
+// order they are produced (pair index n = row * C + channel): two register-to-register halving steps
+//     w = sig_fold16(sig_fold32(t0, t1), sig_fold32(t2, t3))
+// leave in every lane a sum over the 4 lanes l % 16 == const of ONE of the four -- t0, t2, t1, t3 in the lane rows
+// l / 16 = 0, 1, 2, 3 -- so only a quarter of the bytes goes through the LDS: tile[pair][l % 16], 16 x 17 doubles; then
+// lane = pair reads quarter l / 16 of its row (4 doubles) and sig_sum_rows_f64 adds the quarters.  Fixed order.
+// Shares the PipelinedTile's LDS region (its single-row mode serves the rows left over at a block's end): the wave's LDS
+// operations execute in order, so reads issued here are served before any later store of the other form.
+constexpr int kFoldStride = 17;            // doubles between pairs: odd, so the 16 lanes of a quarter read 16 different bank pairs
+
+template <int C>
+struct FoldedGroup {
+    double* put; const double* get; double* dstp; int lane;
+    __device__ __forceinline__ FoldedGroup(double* tile, int lane_, double* dstp_)
+        : put(tile + ((((lane_ >> 4) & 1) << 1) | (lane_ >> 5)) * kFoldStride + (lane_ & 15)),
+          get(tile + (lane_ & 15) * kFoldStride + 4 * (lane_ >> 4)), dstp(dstp_), lane(lane_) {}
+    // the sums with pair indices 4 q .. 4 q + 3 of this lane
+    __device__ __forceinline__ void fold4(int q, double t0, double t1, double t2, double t3) const {
+        put[4 * q * kFoldStride] = sig_fold16(sig_fold32(t0, t1), sig_fold32(t2, t3));
+    }
+    __device__ __forceinline__ void issue(double (&pv)[4]) const {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pv[t] = get[t];
+    }
+    __device__ __forceinline__ void finish(const double (&pv)[4], int64_t row0, int nrows) const {
+        const double s = sig_sum_rows_f64((pv[0] + pv[1]) + (pv[2] + pv[3]));
+        if (lane < nrows * C) dstp[row0 * C + lane] = s;
     }
 };
 

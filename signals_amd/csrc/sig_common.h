@@ -51,6 +51,21 @@ __device__ __forceinline__ double sig_sum_rows_f64(double s) {
     return s;
 }
 
+// Halving steps of a cross-lane sum, two values at a time (gfx950's v_permlane32_swap / v_permlane16_swap exchange lane
+// groups of two registers in one instruction, so no select is needed):
+//   sig_fold32(a, b): lanes 0-31 get a[l] + a[l + 32], lanes 32-63 get b[l - 32] + b[l]
+//   sig_fold16(a, b): rows (16-lane groups) R0, R2 get a summed over (R0, R1) resp. (R2, R3); rows R1, R3 the same of b
+__device__ __forceinline__ double sig_fold32(double a, double b) {
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double sig_fold16(double a, double b) {
+    const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+
 // numpy's float mod for a positive power-of-two divisor d = 1/INV_D (npy_divmod semantics):
 //   m = fmod(t, d)  (exact);  if (m != 0 && m < 0) m += d (ROUNDED, like numpy);  if (m == 0) m = +0
 // Evaluated as  t - d * floor(t * INV_D):  d * floor(..) is exact, and for t < 0 the one rounded subtraction

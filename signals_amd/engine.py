@@ -815,6 +815,32 @@ class _VoiceChain:
                 out.append(float(value.max()) if value.size and np.isfinite(value).all() else float('inf'))
         return out[0] / self.batch.rate, out[1]
 
+    def ordered_by_cutoff(self, ctl, pan, voices_per_lane: int):
+        """(controls, pan) with the voices re-ordered for the bus launch: groups of 64 neighbours in cutoff, dealt round
+        robin over the voice tiles of 64 * voices_per_lane, slot-major (slot i of every lane of a wave = one group).  The bus is a sum
+        over voices, so any order renders the same bus up to the rounding of the sum; this one lets the Sine closed
+        form drop the decayed homogeneous part of whole voice slots (fused_voice.hip: fused_steady_bus_kernel).
+        Built once per parameter upload (it is kept with the closed form's constants)."""
+        import numpy as np
+        v, src = self.channels, self.filt.cutoff.sig
+        if ctl[2].shape[1] != v or not isinstance(src, fixed.Fixed):
+            return ctl, pan
+        cut = np.asarray(src._state.value, dtype=np.float64).reshape(-1)
+        if cut.size != v or not np.isfinite(cut).all():
+            return ctl, pan
+        order = np.argsort(cut, kind='stable')
+        tile = 64 * voices_per_lane
+        tiles = v // tile
+        perm = order.copy()                                                  # a ragged last tile stays lane-major
+        q = np.arange(tiles * tile)
+        # the j-th group of 64 neighbours in cutoff goes to tile j % tiles, slot j // tiles: every wave gets the same mix
+        # of slow- and fast-decaying slots (one wave per SIMD: the launch takes as long as its slowest wave)
+        group, lane = q // 64, q % 64
+        perm[((group % tiles) * 64 + lane) * voices_per_lane + group // tiles] = order[q]
+        index = torch.from_numpy(perm).to(runtime.device())
+        pick = lambda t: t if t is None or t.shape[1] != v else t.index_select(1, index).contiguous()
+        return [pick(t) for t in ctl], pick(pan)
+
     def live_key(self, bus_node=None):
         """identities of the resident control tensors (and the bus gains) as they are NOW -- `resident()` re-uploads an
         edited array, which changes the identity; None if the pattern no longer holds.  The cheap per-block check of the
@@ -915,13 +941,16 @@ class _VoiceChain:
                 return o._launch('sum_bus', lambda: _native.sum_bus(voices_buf, pan_now, out), units=rows * v)
             # the Sine closed form's per-voice constants survive from call to call while the control tensors (held here,
             # so their addresses cannot be recycled), the filter type and min(context, position) are the same
-            key = (tuple(id(t) for t in ctl), self.btype, rate, v, min(CONTEXT, position))
+            key = (tuple(id(t) for t in ctl), id(pan_now), self.btype, rate, v, min(CONTEXT, position))
             held = o._steady_consts
             ready = held is not None and held[0] == key
             if not ready:
                 size = _native.lib().sig_fused_voice_consts_size(v) // 8
                 buf = held[2] if held is not None and held[2].numel() >= size else torch.empty(size, dtype=CTRL_DTYPE, device=dev)
-                o._steady_consts = held = (key, tuple(ctl), buf, self.cycles_per_frame_bound())
+                plan = _native.fused_voice_bus_plan(self.kind, position, v, N, K, CONTEXT)
+                o._steady_consts = held = (key, (tuple(ctl), pan_now), buf, self.cycles_per_frame_bound(),
+                                           self.ordered_by_cutoff(ctl, pan_now, plan['voices_per_lane']))
+            ctl, pan_now = held[4]
             # Past |t| = 2^26 cycles the Sine closed form (and the walker's incremental phase) hands over to the exact
             # per-row phase, wave by wave inside the launch -- correct, but the closed-form kernel's built-in fallback is
             # a plain loop meant for a few waves.  max |hertz| and max |phase| are host-side knowledge: when the launch's

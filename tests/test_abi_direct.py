@@ -57,8 +57,10 @@ def test_c_program_matches_python_engine(blocks, position):
     r = BatchRenderer(bench.build_graph(lcg_params(1024), 0, 1024), 2, 48000)
     r.scan_max_chains = 0
     bus = r.render(position, 256, blocks).cpu().numpy().astype(np.float64)
-    assert np.array_equal(bus[0].astype(np.float32), np.array(c['first'], dtype=np.float32))
-    assert np.array_equal(bus[-1].astype(np.float32), np.array(c['last'], dtype=np.float32))
+    # the engine hands the kernel its voices ordered by cutoff (engine.py: ordered_by_cutoff), the C program in the
+    # order they were drawn: the same bus up to the rounding of the voice sum, i.e. one float32 ulp of a ~0.03 bus
+    assert np.abs(bus[0] - np.array(c['first'], dtype=np.float64)).max() <= 4e-9
+    assert np.abs(bus[-1] - np.array(c['last'], dtype=np.float64)).max() <= 4e-9
     assert abs(bus.sum() - c['sum']) <= 1e-9 * max(1.0, abs(c['sum']))
     assert abs((bus * bus).sum() - c['sumsq']) <= 1e-9 * c['sumsq']
     assert abs(np.abs(bus).max() - c['peak']) < 1e-9 * c['peak']          # printed with 10 significant digits
