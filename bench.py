@@ -250,7 +250,7 @@ def run_config(name: str, steps: int = 12) -> dict:
     import warnings
     warnings.filterwarnings('ignore', category=DeprecationWarning)
     if name == 'C3':
-        V, channels, N, K = 1024, 1, 1024, 256
+        V, channels, N, K = 1024, 1, 1024, 1024              # 1.07 G voice-samples per batch, like the headline's
         p = cfg.c3_params(V)
         node, workload = cfg.c3_graph(p), f'C3: {V}-voice Sawtooth->LowPass->LowPass->(x ADSR)->SumBus(mono), 48 kHz, {N}-frame blocks, {K} blocks per batch'
     else:
@@ -265,7 +265,8 @@ def run_config(name: str, steps: int = 12) -> dict:
         ref = R.sum_bus(R.render_stream(cfg.c3_oracle(p), 0, N, 2, V)).astype(np.float32).astype(np.float64)
         got = first[:2 * N].double().cpu().numpy()
         errs = {str(b): float(np.max(np.abs(got[b * N:(b + 1) * N] - ref[b * N:(b + 1) * N]))) for b in (0, 1)}
-        sample = f'mono bus, blocks 0 and 1 of the first {K}-block batch (all {V} voices) vs the CPU oracle rendered sequentially from 0'
+        sample = (f'mono bus, blocks 0 and 1 of the first {K}-block batch (all {V} voices) vs the CPU oracle rendered sequentially '
+                  f'from 0 (cascades depend on the render history, so later blocks would cost the oracle the whole stream)')
     else:
         oracle = cfg.c5_oracle(p)
         errs = {}
@@ -284,11 +285,17 @@ def run_config(name: str, steps: int = 12) -> dict:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     summ = timer.summary()
-    kernels = kernel_table(summ, lambda k: ALGO_BYTES.get(k.split('[')[0]))
+    from signals_amd import _native
+
+    def bytes_per_unit(kname):
+        if kname.split('[')[0] == 'fused_cascade_bus':                 # one f64 partial per (voice tile, frame, channel), written and re-read, + the bus
+            tiles = -(-V // (64 * _native.fused_cascade_geometry(V, K)[0]))
+            return (tiles * channels * 8 * 2 + channels * 4) / V
+        return ALGO_BYTES.get(kname.split('[')[0])
+    kernels = kernel_table(summ, bytes_per_unit)
     dom = max(summ, key=lambda k: summ[k]['ms'])
     fam = dom.split('[')[0]
-    from signals_amd import _native
-    model = _native.fused_cascade_model(V, N, K) if fam == 'fused_cascade_bus' and hasattr(_native, 'fused_cascade_model') else None
+    model = _native.fused_cascade_model(V, N, K, bus_channels=channels) if fam == 'fused_cascade_bus' else None
     if model is not None:
         roof = valu_roofline(kernels, dom, summ[dom]['units'] / summ[dom]['calls'], model['f64_ops_per_voice_sample'],
                              pmc_traffic(fam), {k: v for k, v in model.items() if k != 'f64_ops_per_voice_sample'})

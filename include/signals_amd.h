@@ -252,6 +252,33 @@ int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t rate, int6
                                  double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
                                  double* consts, int32_t consts_ready);
 
+/* Fused filter cascade + envelope + sum bus (BASELINE config 3's whole graph in one launch):
+ *   out[n,c] = sum_v bus_gains[c,v] * [gain[v] *] [ADSR_v(n) *] Filter2(Filter1(Osc))[n,v]
+ * i.e. Osc._eval (chain/osc.py:26-62), two CritFilter._filter (chain/fx.py:85-121) in series with the reference's
+ * block-cache semantics between them (chain/__init__.py:431-442, SURVEY.md 8a A9: the outer filter's 100 context rows
+ * are the LAST 100 ROWS OF THE INNER FILTER'S PREVIOUS BLOCK, which was cold-started 100 rows before that block),
+ * RingMod with the build-defined ADSR (adsr_params == NULL: none; layout as sig_adsr) and the build-defined SumBus.
+ * `first_history_start`: the frame at which the block in front of `position` started when the stream was rendered
+ * sequentially -- position - previous_block_frames on a continuing stream, position - min(context, position) on a
+ * fresh graph (the reference then renders [position - 100, position) as a block of its own), == position exactly when
+ * position == 0.  Requires block_frames > context and block_frames % (16 / bus_channels) == 0; cutoffs are one
+ * (1,V)|(1,1) row each.  `workspace`: sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes.
+ * Deterministic (fixed summation order, no atomics). */
+int sig_fused_cascade_bus(int osc_kind, int filt1_type, int filt2_type, int32_t rate, int64_t position,
+                          int64_t first_history_start, int32_t block_frames, int32_t nblocks, int32_t context,
+                          int32_t voices,
+                          const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                          const double* cutoff1, int32_t cutoff1_stride, const double* cutoff2, int32_t cutoff2_stride,
+                          const double* gain, int32_t gain_stride,
+                          const double* const* adsr_params, const int32_t* adsr_strides,
+                          const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                          double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+/* Introspection: voices per lane and consecutive blocks per lane sig_fused_cascade_bus uses (every span of blocks walks
+ * one extra block of oscillator + inner filter, the history; bench.py's operation count depends on it). */
+int sig_fused_cascade_geometry(int32_t voices, int32_t nblocks, int32_t* voices_per_lane, int32_t* blocks_per_lane);
+/* Tuning / test hook (process-wide): force voices per lane (1, 2, 4; 0 = heuristic) and blocks per lane (>= 1; 0 = heuristic). */
+int sig_fused_cascade_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane);
+
 /* Latency mode of the same graph for a Sine oscillator: ONE block per launch, rows x voices parallelism (closed form
  * seeded per 16-row chunk), the voice tiles added and the float32 bus written by the last workgroup to finish -- a
  * single launch per block.  `workspace`: device, sig_latency_voice_bus_workspace(voices, block_frames, bus_channels)

@@ -29,7 +29,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_osc_biquad_devpos', 'sig_advance_position', 'sig_adsr_apply', 'sig_biquad_coldstart_env',
            'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
            'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
-           'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk')
+           'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
+           'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning')
 
 
 class NativeError(RuntimeError):
@@ -118,6 +119,15 @@ def lib() -> ctypes.CDLL:
                                             dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_geometry.restype = ctypes.c_int
         L.sig_fused_geometry.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.sig_fused_cascade_bus.restype = ctypes.c_int
+        L.sig_fused_cascade_bus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i64, i32, i32, i32, i32,
+                                            dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                                            dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_cascade_geometry.restype = ctypes.c_int
+        L.sig_fused_cascade_geometry.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.sig_fused_cascade_set_tuning.restype = ctypes.c_int
+        L.sig_fused_cascade_set_tuning.argtypes = [i32, i32]
         L.sig_fused_voice_bus_plan.restype = ctypes.c_int
         L.sig_fused_voice_bus_plan.argtypes = [ctypes.c_int, i64, i32, i32, i32, i32] + [ctypes.POINTER(ctypes.c_int32)] * 3
         L.sig_fused_set_tuning.restype = ctypes.c_int
@@ -510,6 +520,77 @@ def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
            'sig_fused_geometry')
     return vpt.value, span.value
+
+
+def fused_cascade_bus(kind: str, btype1: str, btype2: str, rate: int, position: int, first_history_start: int,
+                      block_frames: int, nblocks: int, context: int, voices: int,
+                      hertz: torch.Tensor, phase: torch.Tensor | None, cutoff1: torch.Tensor, cutoff2: torch.Tensor,
+                      gain: torch.Tensor | None, envelope: dict | None, bus_gains: torch.Tensor | None, out: torch.Tensor,
+                      workspace: torch.Tensor | None = None, status: torch.Tensor | None = None) -> torch.Tensor:
+    """out (nblocks*block_frames, C) f32 <- sum over voices of pan * [gain *] [ADSR *] Filter2(Filter1(Osc)), the two
+    filters in series with the reference's block-cache history between them (sig_fused_cascade_bus)"""
+    _gpu(hertz, phase, cutoff1, cutoff2, gain, bus_gains, out, workspace, status, *(envelope or {}).values())
+    _audio(out, 'fused cascade out')
+    rows, bus = out.shape
+    if out.dtype != torch.float32 or rows != block_frames * nblocks:
+        raise NativeError(f'fused cascade out must be float32 ({block_frames * nblocks}, C), got {tuple(out.shape)} {out.dtype}')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff1, 'cutoff1'), (cutoff2, 'cutoff2'), (gain, 'gain')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    eptrs = estrides = None
+    if envelope is not None:
+        eptrs = (ctypes.c_void_p * 6)()
+        estrides = (ctypes.c_int32 * 6)()
+        for i, name in enumerate(ADSR_PARAMS):
+            eptrs[i], estrides[i] = _ctrl_row(envelope[name], name)
+            if envelope[name].shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {envelope[name].shape[1]} channels for {voices} voices')
+    gp, gld = None, 0
+    if bus_gains is not None:
+        if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus, voices) or bus_gains.stride(1) != 1:
+            raise NativeError(f'bus gains must be float64 ({bus},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+        gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+    elif bus != 1:
+        raise NativeError('a bus without gains is mono')
+    need = lib().sig_fused_voice_bus_workspace(voices, rows, bus)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    _check(lib().sig_fused_cascade_bus(OSC_KINDS[kind], FILT_TYPES[btype1], FILT_TYPES[btype2], rate, position,
+                                       first_history_start, block_frames, nblocks, context, voices, *ptrs, eptrs, estrides,
+                                       gp, gld, bus, workspace.data_ptr(), out.data_ptr(), out.stride(0),
+                                       status.data_ptr() if status is not None else None, _stream(out)),
+           'sig_fused_cascade_bus')
+    return out
+
+
+def fused_cascade_geometry(voices: int, nblocks: int) -> tuple[int, int]:
+    """(voices per lane, blocks per lane) of `fused_cascade_bus` for this problem size"""
+    vpt, span = ctypes.c_int32(), ctypes.c_int32()
+    _check(lib().sig_fused_cascade_geometry(voices, nblocks, ctypes.byref(vpt), ctypes.byref(span)), 'sig_fused_cascade_geometry')
+    return vpt.value, span.value
+
+
+def set_fused_cascade_tuning(voices_per_lane: int = 0, blocks_per_lane: int = 0) -> None:
+    """tuning / test hook (process-wide): force `fused_cascade_bus`'s launch geometry; the defaults restore the heuristic"""
+    _check(lib().sig_fused_cascade_set_tuning(voices_per_lane, blocks_per_lane), 'sig_fused_cascade_set_tuning')
+
+
+def fused_cascade_model(voices: int, block_frames: int, nblocks: int, context: int = 100, bus_channels: int = 1,
+                        osc_ops: float = 6.0, envelope: bool = True) -> dict:
+    """f64-rate VALU instructions per stored voice-sample of `fused_cascade_bus` (bench.py's roofline): the exact-phase
+    oscillator (6 for a Sawtooth: t = q * hertz + phase, t - 0.5, floor, subtract, 2 m - 1) and the inner filter (4) on
+    every row a lane walks -- span * N output rows, one history block of N + context rows per span, context warm-up rows
+    per further block -- the outer filter (4) on N + context rows per block, envelope (3), C bus FMAs and the folded flush"""
+    vpt, span = fused_cascade_geometry(voices, nblocks)
+    n, c = block_frames, context
+    walked = (span * n + n + c) / (span * n)                    # oscillator + inner filter rows per output row
+    warm = (span - 1) * c / (span * n)                          # next-block warm-up chains (inner + outer) beside output rows
+    ops = osc_ops * walked + 4.0 * (walked + warm) + 4.0 * (1.0 + c / n) + (3.0 if envelope else 0.0) + bus_channels \
+        + 17.0 * bus_channels / (16 * vpt)
+    return {'f64_ops_per_voice_sample': ops, 'voices_per_lane': vpt, 'blocks_per_lane': span,
+            'rows_walked_per_output_row': walked}
 
 
 def fused_voice_bus_plan(kind: str, position: int, voices: int, block_frames: int, nblocks: int, context: int) -> dict:

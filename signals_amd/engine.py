@@ -156,12 +156,15 @@ class BatchRenderer:
         self._captured: _CapturedLaunches | None = None
         self.fuse = fuse
         self.fuse_bus = fuse and fuse_bus           # also fold a SumBus on top of the chain into the launch
+        self.fuse_cascade = fuse and fuse_bus       # SumBus([RingMod(] Filter(Filter(Osc)) [, ADSR)]) in one launch (sig_fused_cascade_bus)
         self.node = node
         self.channels = channels
         self.rate = rate
         self.timer = timer
         self._tails: dict[Emitter, tuple[int, torch.Tensor]] = {}    # node -> (end position, last <=100 rows)
         self._stream_end: int | None = None
+        self._prev_block_frames: int | None = None         # N of the previous render (where a fused cascade's history block starts)
+        self._virtual_history = False                      # the previous batch kept its filter history implicit (no tails needed)
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -185,19 +188,22 @@ class BatchRenderer:
                 self._stream_end = position + block_frames * nblocks
                 return launch(position)
             self._replay = None
-        continuing = self._stream_end == position and bool(self._tails)
+        continuing = self._stream_end == position and (bool(self._tails) or self._virtual_history)
         if not continuing:
             self._tails.clear()
+        self._virtual_history = False                      # set again by a launch that keeps its history implicit (fused cascade)
         batch = _Batch(self, position, block_frames, nblocks, continuing)
         out = batch.buffer(self.node, self.channels, 0)
         for node, buf in batch.impure_outputs():
             keep = min(CONTEXT, buf.shape[0])
             self._tails[node] = (position + block_frames * nblocks, buf[buf.shape[0] - keep:].clone())
         self._stream_end = position + block_frames * nblocks
+        self._prev_block_frames = block_frames
         return out
 
     def reset(self) -> None:
         self._tails.clear()
+        self._virtual_history = False
         self._stream_end = None
         self._replay = None
         self._captured = None
@@ -539,7 +545,9 @@ class _Batch:
                 gains = (gains * g) if gains is not None else g.expand(1, voices).contiguous()
                 src_port = top.left
                 self._require(src_port.sig, voices, hist)
-        fused = self._bus_over_filter(node, src_port, gains, hist, rows) if o.fuse and hist == 0 else None
+        fused = self._bus_over_cascade(node, src_port, gains, rows) if o.fuse_cascade and hist == 0 else None
+        if fused is None:
+            fused = self._bus_over_filter(node, src_port, gains, hist, rows) if o.fuse and hist == 0 else None
         if fused is not None:
             return fused
         x = self._operand(src_port, src_port.channels, hist)
@@ -547,6 +555,65 @@ class _Batch:
             raise NotBatchable('SumBus over a one-row input')
         result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
         return o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+    def _bus_over_cascade(self, node, src_port, gains, rows):
+        """SumBus([RingMod(] Filter2(Filter1(Osc)) [, ADSR)]) with block-invariant controls and no other reader of any of
+        them: the whole voice in ONE launch (sig_fused_cascade_bus), nothing per-voice through HBM.  The reference's
+        cache history between the two filters is reproduced inside the kernel from where the previous
+        block started: position - N on a continuing stream, position - min(100, position) on a fresh graph."""
+        o, top, voices, N = self.owner, src_port.sig, src_port.channels, self.N
+        C = node.channels
+        if C not in (1, 2, 4) or N <= CONTEXT or N % (16 // C):
+            return None
+
+        def sole(n, kind):
+            return (isinstance(n, kind) and n.get_state().enabled and len(n.outputs_with_ports) == 1 and (n, voices) not in self._memo)
+        ctl = None
+        f2 = top
+        if sole(top, fx.RingMod) and not _modulated(top):
+            for env_port, x_port in ((top.right, top.left), (top.left, top.right)):
+                env = env_port.sig
+                if sole(env, ext.ADSR) and not _modulated(env) and isinstance(x_port.sig, fx.SingleCritFilter):
+                    ctl = env.control_rows(lambda bound: self._control_const(bound, bound.name))
+                    f2 = x_port.sig
+                    break
+            else:
+                return None
+        if not sole(f2, fx.SingleCritFilter):
+            return None
+        f1 = f2.input.sig
+        if not sole(f1, fx.SingleCritFilter):
+            return None
+        src = f1.input.sig
+        if not sole(src, osc.Osc) or any(not _ctl_const(p) for p in (src.hertz, src.phase, f1.cutoff, f2.cutoff)):
+            return None
+        hertz, phase = self._control_const(src.hertz, 'hertz'), self._control_const(src.phase, 'phase')
+        cut1, cut2 = self._control_const(f1.cutoff, 'cutoff'), self._control_const(f2.cutoff, 'cutoff')
+        if max(hertz.shape[1], phase.shape[1]) != voices or cut1.shape[1] != voices or cut2.shape[1] != voices:
+            return None                                                        # (the reference indexes cutoff[0, i] per channel)
+        if any(t.shape[1] not in (1, voices) for t in (hertz, phase, *(ctl or {}).values())):
+            return None
+        if gains is not None and gains.shape[1] != voices:
+            return None
+        if self.pos == 0:
+            history = 0
+        elif self.continuing and o._prev_block_frames and self.pos - o._prev_block_frames >= 0:
+            history = self.pos - o._prev_block_frames
+        else:
+            history = self.pos - min(CONTEXT, self.pos)
+        result = torch.empty((rows, C), dtype=AUDIO_DTYPE, device=runtime.device())
+        need = _native.lib().sig_fused_voice_bus_workspace(voices, rows, C) // 8
+        if o._workspace is None or o._workspace.numel() < need:
+            o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
+        status = o._status_word(f2)                                            # one word for the launch: both designs report here
+        kind, t1, t2 = src.kind(), str(f1.type()), str(f2.type())
+        o._virtual_history = True
+        out = o._launch(f'fused_cascade_bus[{kind},{t1},{t2}{",env" if ctl else ""}]',
+                        lambda: _native.fused_cascade_bus(kind, t1, t2, self.rate, self.pos, history, N, self.K, CONTEXT, voices,
+                                                          hertz, phase, cut1, cut2, None, ctl, gains, result,
+                                                          workspace=o._workspace, status=status),
+                        units=rows * voices)
+        return out
 
     def _bus_over_filter(self, node, src_port, gains, hist, rows):
         """SumBus(Filter(x)) / SumBus(RingMod(Filter(x), ADSR)) with no other reader of the filter (and of the

@@ -596,6 +596,7 @@ def test_ringmod_with_adsr_in_one_pass():
     bus, p = c3_graph(V)
     timer = KernelTimer()
     r = BatchRenderer(bus, 1, RATE, timer=timer)
+    r.fuse_cascade = False                       # (by default the whole voice is ONE launch: tests/test_gpu_fused_cascade.py)
     got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
     torch.cuda.synchronize()
     names = set(timer.summary())
@@ -630,7 +631,9 @@ def test_ringmod_with_adsr_in_one_pass():
         if stereo:
             b.get_state().gains = pan
         timer = KernelTimer()
-        got = BatchRenderer(b, 2 if stereo else 1, RATE, timer=timer).render(0, N, K).cpu().numpy()
+        rb = BatchRenderer(b, 2 if stereo else 1, RATE, timer=timer)
+        rb.fuse_cascade = False
+        got = rb.render(0, N, K).cpu().numpy()
         torch.cuda.synchronize()
         assert 'biquad_bus[lp]' in set(timer.summary()) and 'sum_bus' not in set(timer.summary()), set(timer.summary())
         chain = R.Filter('lp', R.Filter('hp', R.Osc('Triangle', R.Fixed(p['hertz']), R.Fixed(p['phase'])), R.Fixed(p['cut1'])),

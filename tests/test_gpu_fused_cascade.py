@@ -1,0 +1,186 @@
+"""The fused cascade (sig_fused_cascade_bus, signals_amd/csrc/fused_cascade.hip): Osc -> Filter -> Filter [-> x ADSR]
+-> SumBus in one launch, against the CPU oracle driven like the reference (sequential pulls, block caches: the outer
+filter's context is the inner filter's PREVIOUS block), the reference's own golden cascades, the
+per-node engine schedule and the eager path; continuing streams, fresh starts mid-stream, every launch geometry."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RATE, f32, fix, maxerr, mkosc, stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+    assert torch.cuda.is_available()
+    from signals_amd import _native, runtime
+    runtime.set_device('cuda:0')
+    _native.lib()
+
+
+def params(V, seed):
+    rng = np.random.default_rng(seed)
+    env = dict(attack=rng.uniform(0.001, 0.05, (1, V)), decay=rng.uniform(0.01, 0.2, (1, V)), sustain=rng.uniform(0.2, 0.9, (1, V)),
+               release=rng.uniform(0.02, 0.3, (1, V)), gate_on=rng.uniform(0.0, 0.05, (1, V)), gate_off=rng.uniform(0.06, 0.12, (1, V)))
+    th = rng.uniform(0, np.pi / 2, V)
+    return dict(hertz=rng.uniform(55, 1760, (1, V)), phase=rng.uniform(0, 1, (1, V)), cut1=rng.uniform(200, 8000, (1, V)),
+                cut2=rng.uniform(200, 8000, (1, V)), gain=rng.uniform(0.2, 1.0, (1, V)), env=env, pan=np.stack([np.cos(th), np.sin(th)]))
+
+
+def graph(p, kind='Sawtooth', t1='LowPass', t2='LowPass', env=True, gain=False, pan=None):
+    from signals_amd.chain import ext, fx
+    f1 = getattr(fx, t1)(); f1.input = mkosc(kind, p['hertz'], p['phase']); f1.cutoff = fix(p['cut1'])
+    f2 = getattr(fx, t2)(); f2.input = f1; f2.cutoff = fix(p['cut2'])
+    top = f2
+    if env:
+        a = ext.ADSR()
+        for k, v in p['env'].items():
+            setattr(a, k, fix(v))
+        rm = fx.RingMod(); rm.left = f2; rm.right = a
+        top = rm
+    if gain:
+        g = fx.Gain(); g.left = top; g.right = fix(p['gain'])
+        top = g
+    bus = ext.SumBus(); bus.input = top
+    if pan is not None:
+        bus.get_state().gains = np.ascontiguousarray(pan)
+    return bus
+
+
+def oracle(p, kind='Sawtooth', t1='lp', t2='lp', env=True, gain=False, pan=None):
+    from oracle import chain_ref as R
+    node = R.Filter(t2, R.Filter(t1, R.Osc(kind, R.Fixed(p['hertz']), R.Fixed(p['phase'])), R.Fixed(p['cut1'])), R.Fixed(p['cut2']))
+    if env:
+        node = R.Binary('RingMod', node, R.Adsr(**p['env']))
+    if gain:
+        node = R.Binary('Gain', node, R.Fixed(p['gain']))
+    return node, pan
+
+
+def oracle_stream(p, pos, N, K, V, **kw):
+    from oracle import chain_ref as R
+    node, pan = oracle(p, **kw)
+    return R.sum_bus(R.render_stream(node, pos, N, K, V), pan)
+
+
+def fused(node, channels, timer=None):
+    from signals_amd.engine import BatchRenderer
+    return BatchRenderer(node, channels, RATE, timer=timer)
+
+
+def test_c3_graph_is_one_launch_and_matches_the_oracle():
+    from signals_amd.engine import KernelTimer
+    V, N, K = 48, 1024, 5
+    p = params(V, 3)
+    timer = KernelTimer()
+    r = fused(graph(p), 1, timer)
+    got = r.render(0, N, K).cpu().numpy()
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'fused_cascade_bus[Sawtooth,lp,lp,env]'}, set(timer.summary())
+    ref = oracle_stream(p, 0, N, K, V)
+    scale = np.abs(ref).max()
+    assert scale > 1.0 and maxerr(got, f32(ref)) < 1e-6 * scale
+    # the per-node schedule and the eager pull path (bit-identical to each other) agree to their own float32 roundings
+    from signals_amd.engine import BatchRenderer
+    plain = BatchRenderer(graph(p), 1, RATE, fuse=False).render(0, N, K).cpu().numpy()
+    assert maxerr(got, plain) < 2e-6 * scale
+
+
+def test_continuing_stream_equals_one_long_batch_and_the_oracle():
+    """batches of 3 + 2 + 4 blocks == the oracle's 9 sequential blocks: block 0 of a later batch takes its outer context
+    from the inner filter's previous block (cold-started N + 100 rows earlier), not from a fresh cold start"""
+    V, N = 32, 256
+    p = params(V, 4)
+    p['cut1'][0, :8] = np.linspace(20.0, 120.0, 8)                   # slow filters: the history really matters
+    ref = oracle_stream(p, 0, N, 9, V)
+    r = fused(graph(p), 1)
+    got = np.concatenate([r.render(0, N, 3).cpu().numpy(), r.render(3 * N, N, 2).cpu().numpy(), r.render(5 * N, N, 4).cpu().numpy()])
+    scale = np.abs(ref).max()
+    assert maxerr(got, f32(ref)) < 1e-6 * scale
+    whole = fused(graph(p), 1).render(0, N, 9).cpu().numpy()
+    assert maxerr(whole, got) < 1e-6 * scale
+    # a FRESH renderer started mid-stream answers what a fresh reference graph answers (history block = [p - 100, p))
+    from oracle import chain_ref as R
+    node, _ = oracle(p)
+    fresh_ref = R.sum_bus(R.render_stream(node, 5 * N, N, 2, V))
+    fresh = fused(graph(p), 1).render(5 * N, N, 2).cpu().numpy()
+    assert maxerr(fresh, f32(fresh_ref)) < 1e-6 * scale
+    assert maxerr(fresh, got[5 * N:7 * N]) > 1e-5 * scale            # ... which is NOT what the continuing stream rendered
+
+
+@pytest.mark.parametrize('kind,t1,t2', [('Sawtooth', 'LowPass', 'HighPass'), ('Square', 'HighPass', 'LowPass'),
+                                        ('Triangle', 'LowPass', 'LowPass'), ('Sine', 'HighPass', 'HighPass')])
+def test_waveforms_filter_types_and_bus_widths(kind, t1, t2):
+    V, N, K = 40, 256, 4
+    p = params(V, 7)
+    short = {'LowPass': 'lp', 'HighPass': 'hp'}
+    pan4 = np.random.default_rng(8).uniform(-1, 1, (4, V))
+    for pan in (None, p['pan'], pan4):
+        C = 1 if pan is None else pan.shape[0]
+        for env, gain in ((True, True), (False, False)):
+            got = fused(graph(p, kind, t1, t2, env=env, gain=gain, pan=pan), C).render(0, N, K).cpu().numpy()
+            ref = oracle_stream(p, 0, N, K, V, kind=kind, t1=short[t1], t2=short[t2], env=env, gain=gain, pan=pan)
+            scale = max(1.0, np.abs(ref).max())
+            assert got.shape == (N * K, C) and maxerr(got, f32(ref)) < 1.5e-6 * scale, (kind, C, env)
+
+
+def test_golden_cascades_of_the_reference(golden):
+    """the reference's own 2 x LowPass cascade rendered sequentially (tests/golden/cascade.npz, generated by importing the
+    reference): per-voice outputs are not exposed by the bus kernel, so the check is on the voice sum"""
+    from signals_amd.chain import ext, fx
+    g = golden('cascade')
+
+    def build(t2):
+        f1 = fx.LowPass(); f1.input = mkosc('Sawtooth', g['casc/hertz'], g['casc/phase']); f1.cutoff = fix(g['casc/cut1'])
+        f2 = getattr(fx, t2)(); f2.input = f1; f2.cutoff = fix(g['casc/cut2'])
+        bus = ext.SumBus(); bus.input = f2
+        return bus
+    for N, key in ((256, 'casc/seq_n256'), (1024, 'casc/seq_n1024')):
+        ref = g[key]
+        K = ref.shape[0] // N
+        got = fused(build('LowPass'), 1).render(0, N, K).cpu().numpy()
+        want = ref.sum(axis=1, keepdims=True)
+        assert maxerr(got, f32(want)) < 1e-6 * max(1.0, np.abs(want).max()), key
+    # a fresh graph asked for a late block: the inner filter's history block is [p - 100, p), cold-started at p - 200
+    want = g['casc/fresh_p768'].sum(axis=1, keepdims=True)
+    got = fused(build('HighPass'), 1).render(768, 256, 1).cpu().numpy()
+    assert maxerr(got, f32(want)) < 1e-6 * max(1.0, np.abs(want).max())
+
+
+def test_every_launch_geometry():
+    """voices per lane 1, 2, 4 x spans of 1 .. 5 blocks (forced through the tuning hook: at test sizes the heuristic
+    always spreads the voices thin), ragged voice counts, batch lengths that are not a multiple of the span, mono /
+    stereo, continuing streams"""
+    from signals_amd import _native
+    try:
+        for V, N, K in ((70, 256, 7), (130, 128, 11)):
+            p = params(V, 20 + V)
+            ref = oracle_stream(p, 0, N, K + 3, V, pan=p['pan'])
+            for vpt in (1, 2, 4):
+                for span in (1, 2, 3, 5, 16):
+                    _native.set_fused_cascade_tuning(vpt, span)
+                    assert _native.fused_cascade_geometry(V, K) == (vpt, span)
+                    r = fused(graph(p, pan=p['pan']), 2)
+                    got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(K * N, N, 3).cpu().numpy()])
+                    assert maxerr(got, f32(ref)) < 1.5e-6 * max(1.0, np.abs(ref).max()), (V, N, K, vpt, span)
+    finally:
+        _native.set_fused_cascade_tuning()
+    assert _native.fused_cascade_geometry(1024, 1024) == (4, 4) and _native.fused_cascade_geometry(1024, 256) == (4, 1)
+    assert _native.fused_cascade_geometry(5, 3) == (1, 1)
+
+
+def test_bad_cutoff_in_either_filter_is_reported():
+    from signals_amd import runtime
+    V, N = 16, 256
+    p = params(V, 9)
+    p['cut2'][0, 3] = 30000.0                                          # Wn >= 1: scipy raises ValueError (fx.py:99-121)
+    r = fused(graph(p), 1)                                             # (the renderer owns the device status words)
+    r.render(0, N, 2)
+    with pytest.raises(ValueError):
+        runtime.check_status()
+    p['cut2'][0, 3], p['cut1'][0, 5] = 3000.0, -1.0
+    r2 = fused(graph(p), 1)
+    r2.render(0, N, 2)
+    with pytest.raises(ValueError):
+        runtime.check_status()
