@@ -169,6 +169,7 @@ class BatchRenderer:
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
         self._steady_consts = None                         # (key, control tensors, buffer): closed-form constants kept across calls
+        self._gain_products: dict = {}                     # (id, id) -> (gain row, gain row, their product): Gain on both sides of a filter
         self.latency_kernel = True                         # one-launch blocks for Sine chains in the latency regime
         self._replay = None                                # (graph version, N, K, launch(position)) of a one-launch plan
         self.scan_max_chains = SCAN_MAX_CHAINS             # latency regime threshold (tests set 0 to force the serial kernels)
@@ -808,13 +809,15 @@ class _VoiceChain:
     sig_fused_osc_biquad (chain) or sig_fused_voice_bus (chain + bus); in the latency regime the chain runs as a
     prefix scan and the bus as its own launch, optionally captured into a hipGraph."""
 
-    def __init__(self, batch: _Batch, src, filt, gain_node, bus_node, channels: int):
+    def __init__(self, batch: _Batch, src, filt, gain_node, bus_node, channels: int, pre_gain=None):
         self.batch, self.src, self.filt, self.gain_node, self.bus_node = batch, src, filt, gain_node, bus_node
+        self.pre_gain = pre_gain                                   # a Gain between oscillator and filter, folded into the output gain
         self.channels = channels                                   # voices of the chain
-        self.ports = [src.hertz, src.phase, filt.cutoff] + ([gain_node.right] if gain_node is not None else [])
-        self.involved = [n for n in (src, filt, gain_node, bus_node) if n is not None]
+        self.gain_ports = [g.right for g in (pre_gain, gain_node) if g is not None]
+        self.ports = [src.hertz, src.phase, filt.cutoff] + self.gain_ports
+        self.involved = [n for n in (src, filt, gain_node, bus_node, pre_gain) if n is not None]
         self.kind, self.btype = src.kind(), str(filt.type())
-        self.tag = f'{self.kind},{self.btype}{",gain" if gain_node is not None else ""}'
+        self.tag = f'{self.kind},{self.btype}{",gain" if self.gain_ports else ""}'
 
     # ---- matching
     @classmethod
@@ -840,10 +843,16 @@ class _VoiceChain:
                 return None
         if not isinstance(filt, fx.SingleCritFilter) or not filt.get_state().enabled:
             return None
-        src = filt.input.sig
+        src, pre_gain = filt.input.sig, None
+        if (isinstance(src, fx.Gain) and src.get_state().enabled and _ctl_const(src.right) and isinstance(src.left.sig, osc.Osc)
+                and (src, channels) not in batch._memo):
+            # Filter(Gain(Osc)) = Gain(Filter(Osc)): the filter is linear and starts every block from zero state, so a
+            # block-invariant gain in front of it is a factor of the output weight (lowpass_test.sigs: Triangle -> Gain ->
+            # LowPass).  The Gain may have other readers: they get its rows from the per-node schedule as usual.
+            pre_gain, src = src, src.left.sig
         if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
             return None
-        chain = cls(batch, src, filt, gain_node, bus_node, channels)
+        chain = cls(batch, src, filt, gain_node, bus_node, channels, pre_gain)
         controls = chain.resolve()
         if controls is None or not chain.widths_ok(controls):
             return None
@@ -857,10 +866,19 @@ class _VoiceChain:
         if not all(n.get_state().enabled for n in self.involved):
             return None
         try:
-            rows = [self.batch._control_const(p, p.name) for p in self.ports]
+            rows = [self.batch._control_const(p, p.name) for p in self.ports[:3]]
+            gains = [self.batch._control_const(p, p.name) for p in self.gain_ports]
         except NotBatchable:
             return None
-        return rows + [None] * (4 - len(rows))
+        if len(gains) == 2:
+            # one output gain: the product of the two rows, kept while both uploads are (so that its identity is as stable as
+            # theirs: the closed form's constants are keyed on it)
+            held = self.batch.owner._gain_products.get((id(gains[0]), id(gains[1])))
+            if held is None or held[0] is not gains[0] or held[1] is not gains[1]:
+                self.batch.owner._gain_products.clear()
+                held = self.batch.owner._gain_products[(id(gains[0]), id(gains[1]))] = (gains[0], gains[1], (gains[0] * gains[1]).contiguous())
+            gains = [held[2]]
+        return rows + (gains or [None])
 
     def widths_ok(self, controls) -> bool:
         hertz, phase, cutoff, gain = controls

@@ -718,3 +718,39 @@ def fx_mix(a, b):
     from signals_amd.chain import fx
     m = fx.RingMod(); m.left = a; m.right = b
     return m
+
+
+def test_gain_in_front_of_the_filter_is_folded_into_the_fused_chain(golden):
+    """Filter(Gain(Osc)) = Gain(Filter(Osc)) for a block-invariant gain (the filter is linear and cold-starts every block):
+    one fused launch, with a second Gain behind the filter multiplied in, with and without a bus; 1e-6 vs the oracle"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    hz, ph, cut, gain = g['c2/hertz'], g['c2/phase'], g['c2/cutoff'], g['c2/gain']
+    V, N, K = hz.shape[1], 256, 4
+    pre = np.random.default_rng(3).uniform(0.25, 2.0, (1, V))
+    for kind in ('Sine', 'Square'):
+        for post in (False, True):
+            for bus in (False, True):
+                gn = fx.Gain(); gn.left = mkosc(kind, hz, ph); gn.right = fix(pre)
+                f = fx.HighPass(); f.input = gn; f.cutoff = fix(cut)
+                top = f
+                if post:
+                    top = fx.Gain(); top.left = f; top.right = fix(gain)
+                if bus:
+                    b = ext.SumBus(); b.input = top
+                    top = b
+                timer = KernelTimer()
+                r = BatchRenderer(top, 1 if bus else V, RATE, timer=timer)
+                r.scan_max_chains = 0
+                got = np.concatenate([r.render(512, N, K).cpu().numpy(), r.render(512 + N * K, N, 2).cpu().numpy()])
+                torch.cuda.synchronize()
+                names = set(timer.summary())
+                assert len(names) == 1 and next(iter(names)).split('[')[0] in ('fused_osc_biquad', 'fused_voice_bus'), names
+                node = R.Filter('hp', R.Binary('Gain', R.Osc(kind, R.Fixed(hz), R.Fixed(ph)), R.Fixed(pre)), R.Fixed(cut))
+                if post:
+                    node = R.Binary('Gain', node, R.Fixed(gain))
+                ref = np.concatenate([R.render(node, 512 + i * N, N, V, RATE) for i in range(K + 2)])
+                ref = R.sum_bus(ref) if bus else ref
+                assert maxerr(got, f32(ref)) < 1e-6, (kind, post, bus)

@@ -75,7 +75,22 @@ def test_patches_render_like_the_reference(golden):
     out = sigs.load(DATA / 'lowpass_test.sigs')['7a'].render(3)
     assert np.max(np.abs(out - f32(g['sigs/lowpass_test'][:, :1]))) < 2e-7
     eager = sigs.load(DATA / 'lowpass_test.sigs')['7a'].render(3, batched=False)
-    assert np.array_equal(out, eager)
+    assert np.max(np.abs(eager - f32(g['sigs/lowpass_test'][:, :1]))) < 2e-7
+    assert np.max(np.abs(out - eager)) < 2e-7            # the engine fuses Triangle -> Gain -> LowPass (f64 between the nodes)
+    # ... into ONE launch: the Gain in front of the filter is folded into the fused chain's output weight
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    patch = sigs.load(DATA / 'lowpass_test.sigs')
+    timer = KernelTimer()
+    again = BatchRenderer(patch['7a'].input.sig, 1, 48000, timer=timer).render(0, 256, 3).cpu().numpy()
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'fused_osc_biquad[Triangle,lp,gain]'}, set(timer.summary())
+    assert np.array_equal(again, out)
+    # the patch's Merge reads the Gain too (4b -> 5a.left, 3a -> 5a.right): its rows then come from the per-node schedule
+    timer = KernelTimer()
+    both = BatchRenderer(patch['5a'], 2, 48000, timer=timer).render(0, 256, 3).cpu().numpy()
+    torch.cuda.synchronize()
+    assert 'fused_osc_biquad[Triangle,lp,gain]' in set(timer.summary()) and 'elementwise[Gain]' in set(timer.summary())
+    assert np.max(np.abs(both - f32(g['sigs/lowpass_test']))) < 2e-7
 
 
 @pytest.mark.gpu
