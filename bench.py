@@ -298,7 +298,7 @@ def run_config(name: str, steps: int = 12) -> dict:
     model = _native.fused_cascade_model(V, N, K, bus_channels=channels) if fam == 'fused_cascade_bus' else None
     if model is not None:
         roof = valu_roofline(kernels, dom, summ[dom]['units'] / summ[dom]['calls'], model['f64_ops_per_voice_sample'],
-                             pmc_traffic(fam), {k: v for k, v in model.items() if k != 'f64_ops_per_voice_sample'})
+                             pmc_traffic(f'{name}/{fam}'), {k: v for k, v in model.items() if k != 'f64_ops_per_voice_sample'})
     else:
         roof = hbm_roofline(kernels, dom, pmc_traffic(f'{name}/{fam}'))
         if fam == 'fused_osc_biquad_mix':

@@ -121,8 +121,9 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     using Vec = typename OutVec<VPT>::type;
     __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? kMixTileRows * kMixLdsStride / 2 : 1)];
     const int lane = threadIdx.x & 63;
-    double* tile = lds[(BUS || MIX) ? (threadIdx.x >> 6) : 0];
-    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: block / tile indices in SGPRs
+    double* tile = lds[(BUS || MIX) ? wave : 0];
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
     if (b_first >= a.K) return;                                               // wave-uniform
@@ -253,15 +254,16 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             }
         }
     };
-    auto to_tile = [&](const double (&y)[VPT], double* where) {
+    auto to_tile = [&](const double (&y)[VPT], double* where, int stride = kTileStride) {
 #pragma unroll
         for (int ch = 0; ch < CC; ++ch) {
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < VPT; ++i) acc = fma(wt[ch][i], y[i], acc);
-            where[ch * kTileStride] = acc;
+            where[ch * stride] = acc;
         }
     };
+    sig_bus::FoldedGroup<CC> folded(tile, lane, dstp);                         // whole groups of R rows: sums folded in registers
     auto to_out = [&](const double (&y)[VPT], int64_t out_row) {
         if constexpr (MIX) {                                                   // rows arrive in order: stage, multiply every 32
             ftile[mstaged * kMixLdsStride + lane] = (float)(y[0] * wt[0][0]);
@@ -346,24 +348,29 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             stage.advance();
         };
         while (stage.staged != 0 && done < count) single();                    // until the tile is empty
-        double pend[16];
+        double pend[4];
         int64_t pend_row = 0;
         bool have = false;
-        for (; GROUPED && done + R <= count; done += R) {                      // whole tiles, flush one group behind
-            ensure(R);
+        for (; GROUPED && done + R <= count; done += R) {                      // whole groups: sums in registers, folded across lanes
+            ensure(R);                                                         // (sig_bus::FoldedGroup), the flush one group behind
+            double acc[kPairs];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double x[VPT], y[VPT];
                 gen(x, k);
                 chains(x, y, w0, w1, warm_tag);
-                to_tile(y, stage.at(k));
+                to_tile(y, acc + k * CC, 1);
+#pragma unroll
+                for (int g = 0; g < kPairs / 4; ++g)
+                    if (4 * g + 3 < (k + 1) * CC && 4 * g + 3 >= k * CC)
+                        folded.fold4(g, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                if (k + 1 == R / 2 && have) folded.finish(pend, pend_row, R);
             }
             n_cur += R;
-            if (have) stage.finish(pend, pend_row, R);
-            stage.issue(pend);
+            folded.issue(pend);
             pend_row = stage.first; stage.first += R; have = true;
         }
-        if (have) stage.finish(pend, pend_row, R);
+        if (have) folded.finish(pend, pend_row, R);
         while (done < count) single();
     };
     auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag) {
@@ -438,15 +445,16 @@ __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt,
     return __all(ok);
 }
 
+// the closed form's per-voice constants (see the enum above), derived from the voice's parameters
+struct SteadyVoice { bool ok; double na1, na2, scale, k2c, st, ct, hre, him, nd; M2 T, T0; };
+
 template <bool GAIN>
-__global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* __restrict__ consts)
+__device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int v)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= a.voices) return;
     using sig_biquad::Cx; using sig_biquad::cx_mul; using sig_biquad::cx_div;
+    SteadyVoice r;
     Biquad q;
-    const bool ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
-    if (!ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    r.ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
     const double a1 = q.a1, a2 = q.a2;
     const double d = a.hertz[(int64_t)v * a.hs] / a.rate;
@@ -472,32 +480,44 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
         const M2 t = m2_mul(Ac, Mss);
         return M2{-t.a, -t.b, -t.c, -t.d};
     };
-    const M2 T = make_T(a.ctx);
+    r.T = make_T(a.ctx);
     const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
-    const M2 T0 = (c0 == a.ctx) ? T : make_T(c0);
-    auto put = [&](int k, double x) { consts[(int64_t)k * a.voices + v] = x; };
+    r.T0 = (c0 == a.ctx) ? r.T : make_T(c0);
     // Rows after a cold start until the homogeneous part is below kHomogeneousTol of the voice's full scale, for good:
     // in the coordinates S x in which A is a rotation times the pole radius rho = sqrt(a2) the state shrinks by exactly
     // rho per row, so |yh_n| <= cond(S) rho^n |x_0| with x_0 = minus the steady-state DF2T state, |x_0| <= sqrt(|P|^2 + |Q|^2)
     // (b0-normalised, hence the factor b0).  S^-1 = [[1, 0], [a1/2, d]], d = sqrt(a2 - a1^2/4) (eigenvector (1, a1 + lambda));
     // its condition number from the Frobenius norm and the determinant.  NaN or real poles: never (infinity).
-    double nd = __builtin_inf();
+    r.nd = __builtin_inf();
     {
         const double d2 = a2 - 0.25 * a1 * a1;
-        if (ok && d2 > 0.0 && a2 > 0.0 && a2 < 1.0) {
-            const double d = sqrt(d2), f2 = 1.0 + 0.25 * a1 * a1 + d2;
-            const double kappa = (f2 + sqrt(fmax(f2 * f2 - 4.0 * d2, 0.0))) / (2.0 * d);
+        if (r.ok && d2 > 0.0 && a2 > 0.0 && a2 < 1.0) {
+            const double dd = sqrt(d2), f2 = 1.0 + 0.25 * a1 * a1 + d2;
+            const double kappa = (f2 + sqrt(fmax(f2 * f2 - 4.0 * d2, 0.0))) / (2.0 * dd);
             const double amp = q.b0 * kappa * sqrt(P.re * P.re + P.im * P.im + Q.re * Q.re + Q.im * Q.im);
             const double rows = (amp > kHomogeneousTol) ? log(kHomogeneousTol / amp) / (0.5 * log(a2)) : 0.0;
-            if (rows == rows) nd = ceil(rows) + 1.0;
+            if (rows == rows) r.nd = ceil(rows) + 1.0;
         }
     }
-    put(SC_NA1, -a1); put(SC_NA2, -a2);
-    put(SC_SCALE, GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0);
-    put(SC_K2C, 2.0 * ct); put(SC_ST, st); put(SC_CT, ct);
-    put(SC_HRE, H.re); put(SC_HIM, H.im); put(SC_ND, nd);
-    put(SC_T + 0, T.a); put(SC_T + 1, T.b); put(SC_T + 2, T.c); put(SC_T + 3, T.d);
-    put(SC_T0 + 0, T0.a); put(SC_T0 + 1, T0.b); put(SC_T0 + 2, T0.c); put(SC_T0 + 3, T0.d);
+    r.na1 = -a1; r.na2 = -a2;
+    r.scale = GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0;
+    r.k2c = 2.0 * ct; r.st = st; r.ct = ct; r.hre = H.re; r.him = H.im;
+    return r;
+}
+
+template <bool GAIN>
+__global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* __restrict__ consts)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= a.voices) return;
+    const SteadyVoice c = steady_constants<GAIN>(a, v);
+    if (!c.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    auto put = [&](int k, double x) { consts[(int64_t)k * a.voices + v] = x; };
+    put(SC_NA1, c.na1); put(SC_NA2, c.na2); put(SC_SCALE, c.scale);
+    put(SC_K2C, c.k2c); put(SC_ST, c.st); put(SC_CT, c.ct);
+    put(SC_HRE, c.hre); put(SC_HIM, c.him); put(SC_ND, c.nd);
+    put(SC_T + 0, c.T.a); put(SC_T + 1, c.T.b); put(SC_T + 2, c.T.c); put(SC_T + 3, c.T.d);
+    put(SC_T0 + 0, c.T0.a); put(SC_T0 + 1, c.T0.b); put(SC_T0 + 2, c.T0.c); put(SC_T0 + 3, c.T0.d);
 }
 
 // The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^26 cycles), done inside the
@@ -805,6 +825,144 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     if (stage.staged) stage.now();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The closed form feeding the MixMatrix sink (BASELINE config 5, Sine): one voice per lane, a wave = one 64-voice
+// matrix group over `span` blocks.  Per stored sample 1 (steady two-term recurrence) + 1 (scale) + a conversion, plus 3
+// while the wave's slowest voice still carries its homogeneous part, instead of the walker's 10.45 -- so the launch
+// costs little more than its 64 MFMAs per 32 rows (f64 vector work and the matrix pipe do not overlap on a SIMD).  The
+// per-voice constants are derived by each wave for its own 64 voices (no workspace in this entry point).  Waves with a
+// voice outside the closed form's range walk their blocks row by row with the exact phase.
+template <bool GAIN>
+__global__ __launch_bounds__(256) void fused_steady_mix_kernel(FusedArgs a)
+{
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    __shared__ __attribute__((aligned(16))) float lds[4][kMixTileRows * kMixLdsStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* ftile = lds[wave];
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int vt = (int)(item % a.voice_tiles);
+    const int64_t b_first = (item / a.voice_tiles) * a.span;
+    if (b_first >= a.K) return;                                               // wave-uniform
+    const int nb = (int)((a.K - b_first < (int64_t)a.span) ? a.K - b_first : (int64_t)a.span);
+    const int v = vt * SIG_WAVE + lane;                                       // voices % 64 == 0 (host-checked): every lane is live
+    const int64_t p0 = a.position + b_first * a.N;
+
+    const SteadyVoice sv = steady_constants<GAIN>(a, v);
+    if (!sv.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+
+    // MixMatrix sink (mix_matrix.hip): B operands M[32h + ks][32 jt + i] in 64 VGPRs, rows staged as float32
+    float bm[2][32];
+    {
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            bm[0][ks] = a.mix[(32 * h + ks) * 64 + i];
+            bm[1][ks] = a.mix[(32 * h + ks) * 64 + 32 + i];
+        }
+    }
+    int mstaged = 0;
+    int64_t mrow0 = b_first * a.N;                                             // output row of tile row 0
+    auto mix_flush = [&](int nrows) {
+        const int i = lane & 31, h = lane >> 5;
+        float af[32];                                                          // half-row x[i][32h .. 32h+31]: k(ks, h) = 32h + ks
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(ftile + i * kMixLdsStride + 32 * h + 4 * c);
+            af[4 * c] = t.x; af[4 * c + 1] = t.y; af[4 * c + 2] = t.z; af[4 * c + 3] = t.w;
+        }
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[0][ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[1][ks], acc1, 0, 0, 0);
+        }
+        // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        float* d = a.out + mrow0 * a.out_ld + (int64_t)vt * 64 + i;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (r < nrows) {
+                d[(int64_t)r * a.out_ld] = acc0[reg];
+                d[(int64_t)r * a.out_ld + 32] = acc1[reg];
+            }
+        }
+        mrow0 += nrows;
+        mstaged = 0;
+    };
+    auto stage = [&](double y) {                                               // rows arrive in order: stage, multiply every 32
+        ftile[mstaged * kMixLdsStride + lane] = (float)(y * sv.scale);
+        if (++mstaged == kMixTileRows) mix_flush(kMixTileRows);
+    };
+
+    const double q_first = (double)p0 / a.rate, q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
+    if (!__all(steady_voice_ok(hz, ph, a.rate, sv.st, q_first, q_last) && (a.N >= a.ctx || p0 >= a.ctx))) {
+        // the plain way: every block on its own from zero state over [c context rows | block], exact per-row phase
+        const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
+#pragma unroll 1
+        for (int bi = 0; bi < nb; ++bi) {
+            const int64_t p_b = p0 + (int64_t)bi * a.N;
+            const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll 1
+            for (int r = -c; r < a.N; ++r) {
+                const double t = (double)(p_b + r) / a.rate * hz + ph;         // osc.py:32
+                const double x = (double)sig_osc::osc_sine_f32(t);
+                const double y = x + z0;
+                z0 = fma(sv.na1, y, fma(s2, x, z1));
+                z1 = fma(sv.na2, y, x);
+                if (r >= 0) stage(y);                                          // wave-uniform
+            }
+        }
+        if (mstaged) mix_flush(mstaged);
+        return;
+    }
+
+    // steady-state oscillator at rows p0 - 1 and p0: w = H e^{j phi}, yss_p0 = Im w, yss_{p0-1} = Im(w e^{-j theta})
+    double ya, yb;
+    {
+        const double t_first = q_first * hz + ph;                              // osc.py:32
+        const double f0 = t_first - rint(t_first);                             // exact, |f0| <= 0.5
+        const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
+        const double wr = fma(sv.hre, ur, -(sv.him * ui)), wi = fma(sv.hre, ui, sv.him * ur);
+        yb = wi;
+        ya = fma(wi, sv.ct, -(wr * sv.st));
+    }
+    const int nd_total = wave_max_int((sv.nd < (double)kNeverDrops) ? (int)sv.nd : kNeverDrops);   // NaN: never
+    for (int bi = 0; bi < nb; ++bi) {
+        const bool first = (b_first + bi == 0);
+        const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
+        int live_rows = (nd_total > c) ? nd_total - c : 0;                     // wave-uniform: rows that still carry the homogeneous part
+        live_rows = (live_rows < a.N) ? live_rows : a.N;
+        double z0h = 0.0, z1h = 0.0;
+        if (live_rows > 0) {
+            const M2& t = first ? sv.T0 : sv.T;
+            const double dss = fma(sv.k2c, yb, -ya) - yb;                      // yss_{p+1} - yss_p
+            z0h = fma(t.a, yb, t.b * dss);
+            z1h = fma(t.c, yb, t.d * dss);
+        }
+        int r = 0;
+#pragma unroll 2
+        for (; r < live_rows; ++r) {
+            const double y = yb + z0h, yh = z0h;
+            z0h = fma(sv.na1, yh, z1h);
+            z1h = sv.na2 * yh;
+            const double nx = fma(sv.k2c, yb, -ya);
+            ya = yb; yb = nx;
+            stage(y);
+        }
+#pragma unroll 4
+        for (; r < a.N; ++r) {
+            const double y = yb;
+            const double nx = fma(sv.k2c, yb, -ya);
+            ya = yb; yb = nx;
+            stage(y);
+        }
+    }
+    if (mstaged) mix_flush(mstaged);
+}
+
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
 int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
     return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
@@ -1073,6 +1231,13 @@ int launch_mix(FusedArgs a, hipStream_t stream)
 {
     int vpt;
     pick_geometry(a, 1, vpt, a.span);                                          // one voice per lane: a wave = one matrix group
+    if (KIND == SIG_OSC_SINE && (tuning().steady < 0 ? 1 : tuning().steady)) { // closed form per wave (or its built-in plain fallback)
+        a.voice_tiles = a.voices / SIG_WAVE;
+        const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
+        if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        fused_steady_mix_kernel<GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a);
+        return sig_launch_status();
+    }
     return launch_walk<KIND, GAIN, -1>(a, BusArgs{nullptr, 0, nullptr, 0}, 1, stream);
 }
 

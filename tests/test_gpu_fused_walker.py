@@ -260,13 +260,26 @@ def test_mix_matrix_sink_equals_mix_matrix_over_the_stored_chain_bit_for_bit(kin
     M = torch.tensor(rng.standard_normal((64, 64)), dtype=torch.float32, device='cuda')
     for V, N, K, pos, span in [(128, 256, 5, 37, 1), (128, 256, 5, 0, 4), (64, 100, 3, 512, 2), (192, 50, 7, 0, 1), (64, 17, 5, 3, 8)]:
         p = params(V, 61 + V + N)
-        geometry(1, span)
+        geometry(1, span, steady=0)                          # the row walker feeds the sink: the same float32 rows as the stored chain
         chain = torch.tensor(run_chain(kind, 'lp', p, pos, N, K), device='cuda')
         want = _native.mix_matrix(chain, M, torch.empty_like(chain)).cpu().numpy()
         got = torch.full((K * N, V), float('nan'), device='cuda')
         _native.fused_osc_biquad_mix(kind, 'lp', RATE, pos, N, K, CTX, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
                                      dev(p['gain']), M, got)
         assert np.array_equal(got.cpu().numpy(), want), (V, N, K, pos, span)
+        if kind == 'Sine':
+            # by default a Sine chain reaches the sink through the closed form (fused_steady_mix_kernel): same values to
+            # the rounding of the rows, and within 1e-6 (of the mixed rows' scale) of the oracle's chain times the matrix
+            geometry(1, span, steady=1)
+            closed = torch.full((K * N, V), float('nan'), device='cuda')
+            _native.fused_osc_biquad_mix(kind, 'lp', RATE, pos, N, K, CTX, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
+                                         dev(p['gain']), M, closed)
+            closed = closed.cpu().numpy()
+            scale = float(np.abs(want).max())
+            assert np.isfinite(closed).all() and maxerr(closed, want) < 1e-6 * scale, (V, N, K, pos, span)
+            ref = oracle_chain(kind, 'lp', p, pos, N, K)
+            ref = (ref.reshape(K * N, V // 64, 64) @ M.cpu().numpy().astype(np.float64)).reshape(K * N, V)
+            assert maxerr(closed, f32(ref)) < 2e-6 * scale, (V, N, K, pos, span)
 
 
 def test_closed_form_vs_walker_over_random_parameter_draws():

@@ -22,7 +22,7 @@ import bench_configs as cfg
 
 def c3(V):
     """Saw -> LowPass -> LowPass -> (x ADSR) -> SumBus, N = 1024"""
-    return cfg.c3_graph(cfg.c3_params(V)), 1, 1024, 256, ALGO
+    return cfg.c3_graph(cfg.c3_params(V)), 1, 1024, 1024, ALGO
 
 
 def c5(V):
@@ -60,5 +60,6 @@ def run(name, build, V, steps=10):
 if __name__ == '__main__':
     from signals_amd import runtime
     runtime.set_device('cuda:0')
-    run('C3 saw->LP->LP->xADSR->bus', c3, 1024)
-    run('C5 sine->LP->MixMatrix', c5, 4096)
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    run('C3 saw->LP->LP->xADSR->bus', c3, 1024, steps)
+    run('C5 sine->LP->MixMatrix', c5, 4096, steps)
