@@ -302,9 +302,14 @@ def run_config(name: str, steps: int = 12) -> dict:
     else:
         roof = hbm_roofline(kernels, dom, pmc_traffic(f'{name}/{fam}'))
         if fam == 'fused_osc_biquad_mix':
-            roof['mfma'] = {'flop_per_voice_sample': 128, 'achieved_TFLOPs': 128 * V * N * K / (kernels[dom]['avg_ms'] * 1e-3) / 1e12,
-                            'peak_TFLOPs': 157.3, 'note': 'exact-f32 v_mfma_f32_32x32x2_f32; 16 flop/B: below the f32-MFMA ridge, '
-                                                          'the launch is the walker (f64 VALU) plus the MFMAs, which do not overlap on a SIMD'}
+            # chain + matrix in one launch: paced by the exact-f32 MFMAs (128 flop per voice-sample) plus the f64 vector
+            # phase of the closed form, which do not overlap on a SIMD (tools/ubench/mfma_valu_overlap.hip); the stores
+            # (4 B per voice-sample) hide under them
+            tf = 128 * V * N * K / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
+                    'traffic': roof['traffic'], 'flop_per_voice_sample': 128, 'avg_launch_ms': kernels[dom]['avg_ms'],
+                    'instruction': 'v_mfma_f32_32x32x2_f32 (exact f32; 155 TFLOP/s measured back to back)',
+                    'hbm': {k: roof[k] for k in ('achieved', 'peak', 'unit', 'frac', 'algo_bytes_per_voice_sample')}}
     full_scale = float(np.max(np.abs(ref)))
     return {'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
             'steps': steps, 'roofline': roof, 'kernels': kernels,

@@ -1232,6 +1232,11 @@ int launch_mix(FusedArgs a, hipStream_t stream)
     int vpt;
     pick_geometry(a, 1, vpt, a.span);                                          // one voice per lane: a wave = one matrix group
     if (KIND == SIG_OSC_SINE && (tuning().steady < 0 ? 1 : tuning().steady)) { // closed form per wave (or its built-in plain fallback)
+        // One block per wave unless told otherwise: the closed form has no warm-up rows to amortise over a span, and the
+        // launch is paced by its MFMAs (57 of ~115 us for config 5: 8.6 GFLOP at the 155 TFLOP/s the exact-f32 MFMA
+        // reaches) plus the f64 vector phase, which do not overlap on a SIMD -- more, shorter waves pack the SIMDs better
+        // (span 1 / 2 / 4 / 8: 117 / 133 / 129 / 243 us).
+        if (tuning().span == 0) a.span = 1;
         a.voice_tiles = a.voices / SIG_WAVE;
         const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
         if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
