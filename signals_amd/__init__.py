@@ -50,5 +50,10 @@ def install_as_signals(host_plugins: bool = True) -> None:
     for suffix in names:
         mod = importlib.import_module(__name__ + suffix)
         sys.modules['signals' + suffix] = mod
+    # the command language (signals.map.control) is out of scope; scripts import it next to the chain modules
+    # (scripts/edited_sine.py:9), so the name resolves -- to the `.sigs` loader, its add / con / sink subset
+    sigs = importlib.import_module(__name__ + '.chain.sigs')
+    sys.modules.setdefault('signals.map', sigs)
+    sys.modules.setdefault('signals.map.control', sigs)
     from signals_amd.chain import nodes
     nodes.host_plugins(host_plugins)

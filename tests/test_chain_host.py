@@ -446,3 +446,78 @@ def test_library_scan_finds_plugin_nodes(tmp_path):
     node = cls(); node.get_state().channels = 2
     p = Probe(); p.input = node
     assert np.array_equal(p.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(3, 2))).numpy(), np.ones((3, 2)))
+
+
+def test_null_sink_device_runs_the_callback_loop_like_portaudio_would():
+    """signals.chain.dev.SinkDevice around a null device (reference dev.py:90-179): open / start / stop / close life cycle,
+    one block per callback at frame_position, an exception in the graph stops the stream; Rack lists the device"""
+    import time
+    from signals_amd.chain import dev, discovery
+    rack = discovery.Rack()
+    rack.scan()
+    assert [d.name for d in rack.sinks()] == ['default'] and rack.sources() == []
+    with pytest.raises(discovery.BadDeviceName):
+        rack.get_sink('nope')
+    with pytest.raises(discovery.NotASource):
+        rack.get_source('default')
+    sink = dev.SinkDevice(rack.get_sink('default'), blocksize=64, realtime=False)
+    assert not sink.is_open and not sink.is_active and sink.flags() & SignalFlags.SINK_DEVICE
+    with pytest.raises(dev.BadPlaybackState):
+        sink.stop()
+    with pytest.raises(ValueError):
+        sink.set_state(sink.State(channels=5))             # the device has two channels
+    src = fixed.Fixed(); src.get_state().value = np.array([[0.25, -0.5]])
+    sink.input = src
+    sink.set_state(sink.State(channels=2))
+    played = []
+    sink.on_block = played.append
+    sink.start()
+    assert sink.is_open
+    deadline = time.time() + 10
+    while sink.tell() < 5 and time.time() < deadline:
+        time.sleep(0.001)
+    sink.stop()
+    assert not sink.is_active and sink.is_open and sink.tell() >= 5 and sink.frame_position == 64 * sink.tell()
+    assert len(played) == sink.tell() and played[0].shape == (64, 2) and np.all(played[0] == np.array([[0.25, -0.5]], dtype=np.float32))
+    sink.seek(100)
+    assert sink.tell() == 100
+    with pytest.raises(dev.BadPlaybackState):
+        sink.open()
+    sink.close()
+    assert not sink.is_open
+
+    class Broken(chain.ExplicitChannelsEmitter):
+        @classmethod
+        def flags(cls):
+            return SignalFlags.GENERATOR
+
+        def _eval(self, request):
+            raise RuntimeError('boom')
+    bad = dev.SinkDevice(blocksize=32, realtime=False)
+    bad.log = lambda msg: None
+    bad.input = Broken()
+    bad.start()
+    deadline = time.time() + 10
+    while bad.is_active and time.time() < deadline:
+        time.sleep(0.001)
+    assert not bad.is_active and bad.tell() == 0           # dev.py:174-176: the exception ended the stream
+    bad.destroy()
+    assert not bad.is_open and not bad.input
+
+
+def test_reference_script_imports_resolve():
+    """scripts/edited_sine.py:5-9 of the reference imports these five modules"""
+    import importlib
+    from signals_amd.chain import nodes
+    try:
+        signals_amd.install_as_signals()
+        for name in ('signals.chain.dev', 'signals.chain.discovery', 'signals.chain.fixed', 'signals.chain.osc', 'signals.map.control'):
+            importlib.import_module(name)
+        import signals.chain.discovery
+        rack = signals.chain.discovery.Rack(); rack.scan()
+        import signals.chain.dev
+        sink = signals.chain.dev.SinkDevice(rack.get_sink('default'))
+        sine = signals.chain.osc.Sine(); sink.input = sine
+        assert sink.input.sig is sine
+    finally:
+        nodes.host_plugins(False)

@@ -102,3 +102,36 @@ def test_batched_engine_schedules_around_plugin_nodes():
     eager_clip = stream(clip, 0, N, K, V)
     src, lp, clip = graph(cutoff)
     assert np.array_equal(BatchRenderer(clip, V, RATE).render(0, N, K).cpu().numpy(), eager_clip)
+
+
+def test_null_sink_device_plays_a_gpu_graph_in_real_time(golden):
+    """signals.chain.dev.SinkDevice.start(): the callback thread pulls one fused launch per 256-frame block at the block
+    period, like PortAudio's thread would (dev.py:167-179); what it plays equals an offline render of the same graph"""
+    import time
+    from signals_amd.chain import dev, ext, fx
+    from signals_amd.chain.driver import BlockDriver
+    from helpers import mkosc
+    g = golden('c2')
+
+    def build():
+        f = fx.LowPass(); f.input = mkosc('Sine', g['c2/hertz'], g['c2/phase']); f.cutoff = fix(g['c2/cutoff'])
+        gn = fx.Gain(); gn.left = f; gn.right = fix(g['c2/gain'])
+        bus = ext.SumBus(); bus.input = gn
+        return bus
+    sink = dev.SinkDevice(blocksize=256)                       # real time: 5.3 ms per block
+    sink.input = build()
+    played = []
+    sink.on_block = played.append
+    t0 = time.perf_counter()
+    sink.start()
+    while sink.tell() < 12 and time.perf_counter() - t0 < 20:
+        time.sleep(0.002)
+    sink.stop()
+    elapsed = time.perf_counter() - t0
+    n = len(played)
+    assert n >= 12 and sink.tell() == n and not sink.is_active
+    assert elapsed > 10 * 256 / 48000                            # paced by the block period, not free-running
+    offline = BlockDriver(rate=48000, blocksize=256); offline.input = build()
+    want = offline.render(n)
+    assert np.array_equal(np.concatenate(played), want)
+    sink.destroy()
