@@ -192,6 +192,26 @@ int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t posi
                          const double* gain, int32_t gain_stride,
                          float* out, int64_t out_ld, int32_t* status, void* stream);
 
+/* The fused chain / chain + bus with cutoff and gain read PER BLOCK: the reference reads a control port once per block,
+ * at the block's position (forward_at_block_rate, chain/__init__.py:305-306), so an LFO on a cutoff or a tremolo gives
+ * every block its own filter design and gain.  cutoff_rows / gain_rows: 1 (one row for the launch) or nblocks (row b
+ * for block b, rows contiguous: row b of a per-voice parameter starts at + b * voices, of a broadcast one at + b).
+ * Always the row-by-row span walker (the next block's warm-up chain runs with the next block's design); gain may be
+ * NULL; bus_channels 1 or 2.  hertz and phase stay one row: a modulated oscillator is not position-pure. */
+int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                              int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                              const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                              const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                              const double* gain, int32_t gain_stride, int32_t gain_rows,
+                              float* out, int64_t out_ld, int32_t* status, void* stream);
+int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                             const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                             const double* gain, int32_t gain_stride, int32_t gain_rows,
+                             const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                             double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* hipGraph support for the launch-bound latency loop (one block per pull): the same chain with the frame
  * position read from DEVICE memory, plus a one-thread kernel that advances it, so a captured graph
  * [chain(position_dev) -> bus -> position_dev += block_frames*nblocks] replays unchanged block after block. */

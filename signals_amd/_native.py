@@ -30,7 +30,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_geometry', 'sig_biquad_coldstart_bus', 'sig_fused_osc_biquad_mix', 'sig_latency_voice_bus',
            'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
            'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
-           'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning')
+           'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
+           'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows')
 
 
 class NativeError(RuntimeError):
@@ -126,6 +127,12 @@ def lib() -> ctypes.CDLL:
                                             dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_cascade_geometry.restype = ctypes.c_int
         L.sig_fused_cascade_geometry.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.sig_fused_osc_biquad_rows.restype = ctypes.c_int
+        L.sig_fused_osc_biquad_rows.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                                dp, i32, dp, i32, dp, i32, i32, dp, i32, i32, vp, i64, vp, vp]
+        L.sig_fused_voice_bus_rows.restype = ctypes.c_int
+        L.sig_fused_voice_bus_rows.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                               dp, i32, dp, i32, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_cascade_set_tuning.restype = ctypes.c_int
         L.sig_fused_cascade_set_tuning.argtypes = [i32, i32]
         L.sig_fused_voice_bus_plan.restype = ctypes.c_int
@@ -520,6 +527,58 @@ def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -
     _check(lib().sig_fused_geometry(voices, block_frames, nblocks, context, ctypes.byref(vpt), ctypes.byref(span)),
            'sig_fused_geometry')
     return vpt.value, span.value
+
+
+def _param_rows(t: torch.Tensor | None, what: str, voices: int, nblocks: int):
+    """(ptr, stride, rows) of a per-block parameter: float64 (1|nblocks, V|1), rows contiguous"""
+    if t is None:
+        return None, 0, 1
+    if t.dtype != torch.float64 or t.dim() != 2 or not t.is_contiguous() or t.shape[1] not in (1, voices) or t.shape[0] not in (1, nblocks):
+        raise NativeError(f'{what}: per-block parameters are contiguous float64 (1|{nblocks}, 1|{voices}), got {tuple(t.shape)} {t.dtype}')
+    return t.data_ptr(), (0 if t.shape[1] == 1 else 1), t.shape[0]
+
+
+def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int, voices: int,
+               hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
+               out: torch.Tensor, bus_gains: torch.Tensor | None = None, bus: bool = False,
+               workspace: torch.Tensor | None = None, status: torch.Tensor | None = None) -> torch.Tensor:
+    """[gain *] Filter(Osc) with cutoff / gain rows read per block: out (nblocks*block_frames, voices) f32
+    (sig_fused_osc_biquad_rows), or with `bus` the sum over voices weighted by bus_gains, out (.., C) (sig_fused_voice_bus_rows)"""
+    _gpu(hertz, phase, cutoff, gain, out, bus_gains, workspace, status)
+    _audio(out, 'fused rows out')
+    rows = out.shape[0]
+    if out.dtype != torch.float32 or rows != block_frames * nblocks:
+        raise NativeError(f'fused rows out must be float32 ({block_frames * nblocks}, .), got {tuple(out.shape)} {out.dtype}')
+    ptrs = []
+    for row, name in ((hertz, 'hertz'), (phase, 'phase')):
+        if row is not None and row.shape[1] not in (1, voices):
+            raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+        ptrs.extend(_ctrl_row(row, name))
+    cp, cs, crows = _param_rows(cutoff, 'cutoff', voices, nblocks)
+    gp, gs, grows = _param_rows(gain, 'gain', voices, nblocks)
+    st = status.data_ptr() if status is not None else None
+    if not bus:
+        if out.shape[1] != voices:
+            raise NativeError(f'fused rows out has {out.shape[1]} channels for {voices} voices')
+        _check(lib().sig_fused_osc_biquad_rows(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
+                                               voices, *ptrs, cp, cs, crows, gp, gs, grows, out.data_ptr(), out.stride(0), st,
+                                               _stream(out)), 'sig_fused_osc_biquad_rows')
+        return out
+    C = out.shape[1]
+    bp, bld = None, 0
+    if bus_gains is not None:
+        if bus_gains.dtype != torch.float64 or bus_gains.shape != (C, voices) or bus_gains.stride(1) != 1:
+            raise NativeError(f'bus gains must be float64 ({C},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+        bp, bld = bus_gains.data_ptr(), bus_gains.stride(0)
+    elif C != 1:
+        raise NativeError('a bus without gains is mono')
+    need = lib().sig_fused_voice_bus_workspace(voices, rows, C)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    _check(lib().sig_fused_voice_bus_rows(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
+                                          *ptrs, cp, cs, crows, gp, gs, grows, bp, bld, C, workspace.data_ptr(), out.data_ptr(),
+                                          out.stride(0), st, _stream(out)), 'sig_fused_voice_bus_rows')
+    return out
 
 
 def fused_cascade_bus(kind: str, btype1: str, btype2: str, rate: int, position: int, first_history_start: int,

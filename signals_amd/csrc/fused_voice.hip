@@ -78,6 +78,7 @@ struct FusedArgs {
     double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
     int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
+    int cutoff_rows = 1, gain_rows = 1;      // > 1: one (1,V)|(1,1) parameter row PER BLOCK (sig_fused_*_rows), row b at + b * (stride ? voices : 1)
 };
 
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
@@ -110,7 +111,10 @@ __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt,
 // exactly as mix_matrix.hip does (same fragment layout, same k order, same exact-f32 MFMA), then stored.  The
 // per-voice rows never touch HBM, and the walker's f64 VALU work of one wave overlaps the MFMAs of the other
 // wave on the SIMD.
-template <int KIND, int VPT, bool GAIN, int C>
+// ROWS: cutoff and gain are read per block (the reference reads a control port once per block, at the block's position:
+// chain/__init__.py:305-306 -- an LFO on a cutoff, a tremolo); the filter is then designed per block, the next block's
+// warm-up chain with the next block's design.  GAIN is ignored (a null gain pointer means 1).
+template <int KIND, int VPT, bool GAIN, int C, bool ROWS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
 void fused_walk_kernel(FusedArgs a, BusArgs bus)
 {
@@ -137,22 +141,30 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
 
     double na1[VPT], na2[VPT], z0[VPT], z1[VPT], wt[CC][VPT];
-    bool ok = true, any_live = false;
+    double wna1[ROWS ? VPT : 1], wna2[ROWS ? VPT : 1], wwt[ROWS ? CC : 1][ROWS ? VPT : 1];   // ROWS: the next block's design and weights
+    // the filter and the output weights of block b (ROWS: from parameter row b)
+    auto design_block = [&](int64_t b, double* n1, double* n2, auto weights) {
+        bool ok = true, any_live = false;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const bool live = v0 + i < a.voices;
-        const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
-        any_live |= live;
-        Biquad q;
-        ok &= design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q) || !live;
-        na1[i] = -q.a1; na2[i] = -q.a2;
-        const double scale = GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0;
+        for (int i = 0; i < VPT; ++i) {
+            const bool live = v0 + i < a.voices;
+            const int v = live ? v0 + i : vc;                                  // dead voices shadow a live one ...
+            any_live |= live;
+            const int64_t crow = (ROWS && a.cutoff_rows > 1) ? b * (int64_t)(a.cs ? a.voices : 1) : 0;
+            const int64_t grow = (ROWS && a.gain_rows > 1) ? b * (int64_t)(a.gs ? a.voices : 1) : 0;
+            Biquad q;
+            ok &= design_butter2(a.type, a.cutoff[crow + (int64_t)v * a.cs], a.rate, q) || !live;
+            n1[i] = -q.a1; n2[i] = -q.a2;
+            const double scale = (ROWS ? a.gain != nullptr : GAIN) ? q.b0 * a.gain[grow + (int64_t)v * a.gs] : q.b0;
 #pragma unroll
-        for (int ch = 0; ch < CC; ++ch)                                        // ... with weight exactly 0 on the bus
-            wt[ch][i] = BUS ? (live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0) : scale;
-        z0[i] = z1[i] = 0.0;
-    }
-    if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+            for (int ch = 0; ch < CC; ++ch)                                    // ... with weight exactly 0 on the bus
+                weights(ch, i, BUS ? (live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0) : scale);
+        }
+        if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    };
+    design_block(b_first, na1, na2, [&](int ch, int i, double w) { wt[ch][i] = w; });
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) z0[i] = z1[i] = 0.0;
 
     // hertz / phase of the lane's voices (re-read where needed rather than kept live across the row loops)
     auto load_hz_ph = [&](double (&hz)[VPT], double (&ph)[VPT]) {
@@ -249,8 +261,8 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             z1[i] = fma(na2[i], y[i], x[i]);
             if (WARM) {
                 const double yw = x[i] + w0[i];
-                w0[i] = fma(na1[i], yw, fma(s2, x[i], w1[i]));
-                w1[i] = fma(na2[i], yw, x[i]);
+                w0[i] = fma(ROWS ? wna1[i] : na1[i], yw, fma(s2, x[i], w1[i]));
+                w1[i] = fma(ROWS ? wna2[i] : na2[i], yw, x[i]);
             }
         }
     };
@@ -387,9 +399,18 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             double w0[VPT], w1[VPT];                                           // the next block's chain, from zero state
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { w0[i] = 0.0; w1[i] = 0.0; }
+            if constexpr (ROWS) design_block(b_first + bi + 1, wna1, wna2, [&](int ch, int i, double w) { wwt[ch][i] = w; });
             walk_any(tail, orow + a.N - tail, w0, w1, std::true_type{}, std::true_type{});
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { z0[i] = w0[i]; z1[i] = w1[i]; }
+            if constexpr (ROWS) {
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    na1[i] = wna1[i]; na2[i] = wna2[i];
+#pragma unroll
+                    for (int ch = 0; ch < CC; ++ch) wt[ch][i] = wwt[ch][i];
+                }
+            }
         }
     }
     if (BUS && stage.staged) stage.now();
@@ -1001,23 +1022,54 @@ void pick_geometry(const FusedArgs& a, int max_vpt, int& vpt, int& span) {
     if (env_span >= 1) span = (env_span <= max_span) ? env_span : max_span;
 }
 
-template <int KIND, bool GAIN, int C>
+template <int KIND, bool GAIN, int C, bool ROWS = false>
 int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
 {
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     if constexpr (C < 0) {
-        fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus);
+        fused_walk_kernel<KIND, 1, GAIN, C, ROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus);
     } else {
         switch (vpt) {
-            case 1: fused_walk_kernel<KIND, 1, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            case 2: fused_walk_kernel<KIND, 2, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            case 4: fused_walk_kernel<KIND, 4, GAIN, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 1: fused_walk_kernel<KIND, 1, GAIN, C, ROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 2: fused_walk_kernel<KIND, 2, GAIN, C, ROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+            case 4: fused_walk_kernel<KIND, 4, GAIN, C, ROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             default: return (int)hipErrorInvalidValue;
         }
     }
     return sig_launch_status();
+}
+
+// the per-block-parameter entry points (sig_fused_osc_biquad_rows, sig_fused_voice_bus_rows): always the walker
+template <int KIND, int C>
+int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
+{
+    auto ok = [&](int vpt) {
+        return C > 0 || ((a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0));
+    };
+    int max_vpt = 4;
+    while (max_vpt > 1 && !ok(max_vpt)) max_vpt >>= 1;
+    int vpt;
+    pick_geometry(a, max_vpt, vpt, a.span);
+    const int err = launch_walk<KIND, false, C, true>(a, bus, vpt, stream);
+    if (err || C == 0) return err;
+    const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+    return sig_bus::launch_partials<(C > 0 ? C : 1)>(bus.partials, tiles, bus.rows, out, out_ld, stream);
+}
+
+template <int C>
+int dispatch_rows_kind(int kind, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
+{
+    switch (kind) {
+        case SIG_OSC_SINE: return launch_rows<SIG_OSC_SINE, C>(a, bus, out, out_ld, s);
+#ifndef SIG_TUNE_SINE_ONLY
+        case SIG_OSC_SQUARE: return launch_rows<SIG_OSC_SQUARE, C>(a, bus, out, out_ld, s);
+        case SIG_OSC_SAWTOOTH: return launch_rows<SIG_OSC_SAWTOOTH, C>(a, bus, out, out_ld, s);
+        case SIG_OSC_TRIANGLE: return launch_rows<SIG_OSC_TRIANGLE, C>(a, bus, out, out_ld, s);
+#endif
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 // What sig_fused_voice_bus launches for this problem: voices per lane, blocks per lane, and whether the Sine closed
@@ -1293,6 +1345,54 @@ extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, i
                 out, out_ld, 0, status};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
+}
+
+extern "C" int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                         const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                         const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                         float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                out, out_ld, 0, status};
+    a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
+    return dispatch_rows_kind<0>(osc_kind, a, BusArgs{nullptr, 0, nullptr, 0}, out, out_ld, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                        const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                        const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                        const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                        const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                        double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels);
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
+    SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                nullptr, 0, 0, status};
+    a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
+    BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (bus_channels) {
+        case 1: return dispatch_rows_kind<1>(osc_kind, a, bus, out, out_ld, s);
+        case 2: return dispatch_rows_kind<2>(osc_kind, a, bus, out, out_ld, s);
+    }
+    return (int)hipErrorInvalidValue;                                          // (4-channel buses: the per-node schedule)
 }
 
 extern "C" int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const int64_t* position_dev,

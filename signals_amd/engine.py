@@ -817,7 +817,8 @@ class _VoiceChain:
         self.ports = [src.hertz, src.phase, filt.cutoff] + self.gain_ports
         self.involved = [n for n in (src, filt, gain_node, bus_node, pre_gain) if n is not None]
         self.kind, self.btype = src.kind(), str(filt.type())
-        self.tag = f'{self.kind},{self.btype}{",gain" if self.gain_ports else ""}'
+        self.modulated = any(not _ctl_const(p) for p in [filt.cutoff] + self.gain_ports)   # per-block parameter rows
+        self.tag = f'{self.kind},{self.btype}{",gain" if self.gain_ports else ""}{",per-block" if self.modulated else ""}'
 
     # ---- matching
     @classmethod
@@ -866,7 +867,15 @@ class _VoiceChain:
         if not all(n.get_state().enabled for n in self.involved):
             return None
         try:
-            rows = [self.batch._control_const(p, p.name) for p in self.ports[:3]]
+            rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]          # a modulated oscillator is not position-pure
+            if self.modulated:
+                # cutoff / gain driven by a computed block-rate signal (an LFO sweep, a tremolo): K rows, one per block
+                rows.append(as_control(self.batch._control(self.filt.cutoff, 'cutoff')))
+                gains = [as_control(self.batch._control(p, p.name)) for p in self.gain_ports]
+                if len(gains) == 2:
+                    gains = [(gains[0] * gains[1]).contiguous()]
+                return rows + (gains or [None])
+            rows.append(self.batch._control_const(self.filt.cutoff, 'cutoff'))
             gains = [self.batch._control_const(p, p.name) for p in self.gain_ports]
         except NotBatchable:
             return None
@@ -958,6 +967,10 @@ class _VoiceChain:
         name = f'fused_osc_biquad[{self.tag}]'
 
         def run(position, ctl, out):
+            if self.modulated:
+                return o._launch(name, lambda: _native.fused_rows(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
+                                                                  ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
+                                 units=rows * v)
             return o._launch(name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
                                                                     ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
                              units=rows * v)
@@ -975,7 +988,7 @@ class _VoiceChain:
                 o._replay = None
                 return o.render(position, N, K)                  # pattern no longer holds: re-plan
             return run(position, ctl, torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev))
-        if node is o.node:
+        if node is o.node and not self.modulated:                      # (a replay would re-read the control rows at a stale position)
             o._remember_replay(N, K, replay)
         return run(b.pos, controls, torch.empty((rows, v), dtype=AUDIO_DTYPE, device=dev))
 
@@ -983,6 +996,8 @@ class _VoiceChain:
     def launch_mix(self, mix_node, controls) -> torch.Tensor:
         b, o = self.batch, self.batch.owner
         N, K, v = b.N, b.K, self.channels
+        if self.modulated:
+            return None                                             # per-block rows: the chain runs fused, the matrix as its own launch
         out = torch.empty((N * K, v), dtype=AUDIO_DTYPE, device=runtime.device())
         matrix, status = mix_node.resident_matrix(), o._status_word(self.filt)
         return o._launch(f'fused_osc_biquad_mix[{self.tag}]',
@@ -1003,6 +1018,14 @@ class _VoiceChain:
         need = _native.lib().sig_fused_voice_bus_workspace(v, rows, bus_c) // 8
         if o._workspace is None or o._workspace.numel() < need:
             o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=dev)
+        if self.modulated:
+            if bus_c not in (1, 2):
+                return None
+            out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
+            return o._launch(f'fused_voice_bus[{self.tag}]',
+                             lambda: _native.fused_rows(self.kind, self.btype, rate, b.pos, N, K, CONTEXT, v, controls[0], controls[1],
+                                                        controls[2], controls[3], out, bus_gains=pan, bus=True,
+                                                        workspace=o._workspace, status=status), units=rows * v)
         # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs as a
         # time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
         small = v * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS

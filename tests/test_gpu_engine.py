@@ -754,3 +754,58 @@ def test_gain_in_front_of_the_filter_is_folded_into_the_fused_chain(golden):
                 ref = np.concatenate([R.render(node, 512 + i * N, N, V, RATE) for i in range(K + 2)])
                 ref = R.sum_bus(ref) if bus else ref
                 assert maxerr(got, f32(ref)) < 1e-6, (kind, post, bus)
+
+
+def test_lfo_swept_cutoff_and_tremolo_run_in_the_fused_chain(golden):
+    """cutoff and gain driven by block-rate signals (an LFO sweep, a tremolo: read once per block at the block's position,
+    chain/__init__.py:305-306) over a position-pure oscillator: the control subgraph is evaluated for all K blocks in
+    block-rate launches and the voice chain stays ONE launch with per-block parameter rows (sig_fused_osc_biquad_rows /
+    sig_fused_voice_bus_rows): every block its own filter design, the next block's warm-up with the next block's design"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    V, N = 32, 256
+    hz, ph, cut, gain = g['c2/hertz'][:, :V], g['c2/phase'][:, :V], g['c2/cutoff'][:, :V], g['c2/gain'][:, :V]
+    assert hz.shape[1] == V
+
+    def build(kind, bus, tremolo):
+        lfo = mkosc('Sine', [[1.7]])
+        sweep = fx.Mix(); sweep.left = lfo; sweep.right = fix([[1.0]]); sweep.mix = fix([[0.4]])      # 0.4 lfo + 0.6
+        cutoff = fx.RingMod(); cutoff.left = sweep; cutoff.right = fix(cut)                           # (1, V) per block
+        f = fx.LowPass(); f.input = mkosc(kind, hz, ph); f.cutoff = cutoff
+        top = f
+        if tremolo:
+            trem = fx.Mix(); trem.left = mkosc('Triangle', [[3.1]]); trem.right = fix([[1.0]]); trem.mix = fix([[0.3]])
+            depth = fx.RingMod(); depth.left = trem; depth.right = fix(gain)
+            top = fx.Gain(); top.left = f; top.right = depth
+        if bus:
+            b = ext.SumBus(); b.input = top
+            top = b
+        return top
+
+    def oracle(kind, bus, tremolo):
+        sweep = R.Binary('Mix', R.Osc('Sine', R.Fixed([[1.7]])), R.Fixed([[1.0]]), R.Fixed([[0.4]]))
+        node = R.Filter('lp', R.Osc(kind, R.Fixed(hz), R.Fixed(ph)), R.Binary('RingMod', sweep, R.Fixed(cut)))
+        if tremolo:
+            trem = R.Binary('Mix', R.Osc('Triangle', R.Fixed([[3.1]])), R.Fixed([[1.0]]), R.Fixed([[0.3]]))
+            node = R.Binary('Gain', node, R.Binary('RingMod', trem, R.Fixed(gain)))
+        return node
+
+    for kind in ('Sine', 'Sawtooth'):
+        for bus in (False, True):
+            for tremolo in (False, True):
+                timer = KernelTimer()
+                r = BatchRenderer(build(kind, bus, tremolo), 1 if bus else V, RATE, timer=timer)
+                got = np.concatenate([r.render(4096, N, 5).cpu().numpy(), r.render(4096 + 5 * N, N, 3).cpu().numpy(),
+                                      r.render(4096 + 8 * N, N, 1).cpu().numpy()])
+                torch.cuda.synchronize()
+                names = set(timer.summary())
+                fused = [n for n in names if n.startswith(('fused_osc_biquad[', 'fused_voice_bus['))]
+                assert fused and all('per-block' in n for n in fused), names
+                assert not names & {'biquad_coldstart[lp]', 'sum_bus', 'elementwise[Gain]', 'elementwise[Gain,per-block]'}, names
+                ref = R.render_stream(oracle(kind, bus, tremolo), 4096, N, 9, V)
+                ref = R.sum_bus(ref) if bus else ref
+                assert maxerr(got, f32(ref)) < 1e-6, (kind, bus, tremolo)
+                eager = stream(build(kind, bus, tremolo), 4096, N, 9, 1 if bus else V)
+                assert maxerr(got, eager) < 1e-6, (kind, bus, tremolo)

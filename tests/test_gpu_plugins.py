@@ -132,6 +132,8 @@ def test_null_sink_device_plays_a_gpu_graph_in_real_time(golden):
     assert n >= 12 and sink.tell() == n and not sink.is_active
     assert elapsed > 10 * 256 / 48000                            # paced by the block period, not free-running
     offline = BlockDriver(rate=48000, blocksize=256); offline.input = build()
-    want = offline.render(n)
+    want = np.concatenate([offline.pull() for _ in range(n)])            # the same one-launch block kernel, block by block
     assert np.array_equal(np.concatenate(played), want)
+    batch = BlockDriver(rate=48000, blocksize=256); batch.input = build()
+    assert np.abs(batch.render(n) - want).max() < 1e-7                   # ... and the batch kernels, to rounding
     sink.destroy()
