@@ -212,6 +212,28 @@ int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t 
                              const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
                              double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
 
+/* The same two entry points for a filter that reads TWO oscillators through an element-wise node: pair_op 1 =
+ * Mix(A, B, mix): mix * A + (1 - mix) * B with mix one (1,V)|(1,1) row (Mix._eval, fx.py:35-40); pair_op 2 =
+ * RingMod(A, B): A * B (fx.py:43-46; mix ignored, may be NULL).  A = (osc_kind, hertz, phase), B = (osc2_kind, hertz2,
+ * phase2); both evaluated per row in the walker (B always with the exact per-row phase), nothing per-voice stored. */
+int sig_fused_osc_pair_biquad(int osc_kind, int osc2_kind, int pair_op, int filt_type, int32_t rate, int64_t position,
+                              int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                              const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                              const double* hertz2, int32_t hertz2_stride, const double* phase2, int32_t phase2_stride,
+                              const double* mix, int32_t mix_stride,
+                              const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                              const double* gain, int32_t gain_stride, int32_t gain_rows,
+                              float* out, int64_t out_ld, int32_t* status, void* stream);
+int sig_fused_voice_pair_bus(int osc_kind, int osc2_kind, int pair_op, int filt_type, int32_t rate, int64_t position,
+                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                             const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                             const double* hertz2, int32_t hertz2_stride, const double* phase2, int32_t phase2_stride,
+                             const double* mix, int32_t mix_stride,
+                             const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                             const double* gain, int32_t gain_stride, int32_t gain_rows,
+                             const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                             double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
 /* hipGraph support for the launch-bound latency loop (one block per pull): the same chain with the frame
  * position read from DEVICE memory, plus a one-thread kernel that advances it, so a captured graph
  * [chain(position_dev) -> bus -> position_dev += block_frames*nblocks] replays unchanged block after block. */

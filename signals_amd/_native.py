@@ -31,7 +31,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
            'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
-           'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows')
+           'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus')
 
 
 class NativeError(RuntimeError):
@@ -133,6 +133,14 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus_rows.restype = ctypes.c_int
         L.sig_fused_voice_bus_rows.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                dp, i32, dp, i32, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
+        L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                                dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
+                                                dp, i32, i32, dp, i32, i32, vp, i64, vp, vp]
+        L.sig_fused_voice_pair_bus.restype = ctypes.c_int
+        L.sig_fused_voice_pair_bus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                               dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
+                                               dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_cascade_set_tuning.restype = ctypes.c_int
         L.sig_fused_cascade_set_tuning.argtypes = [i32, i32]
         L.sig_fused_voice_bus_plan.restype = ctypes.c_int
@@ -541,10 +549,13 @@ def _param_rows(t: torch.Tensor | None, what: str, voices: int, nblocks: int):
 def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: int, nblocks: int, context: int, voices: int,
                hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
                out: torch.Tensor, bus_gains: torch.Tensor | None = None, bus: bool = False,
-               workspace: torch.Tensor | None = None, status: torch.Tensor | None = None) -> torch.Tensor:
+               workspace: torch.Tensor | None = None, status: torch.Tensor | None = None,
+               pair: tuple | None = None) -> torch.Tensor:
     """[gain *] Filter(Osc) with cutoff / gain rows read per block: out (nblocks*block_frames, voices) f32
-    (sig_fused_osc_biquad_rows), or with `bus` the sum over voices weighted by bus_gains, out (.., C) (sig_fused_voice_bus_rows)"""
-    _gpu(hertz, phase, cutoff, gain, out, bus_gains, workspace, status)
+    (sig_fused_osc_biquad_rows), or with `bus` the sum over voices weighted by bus_gains, out (.., C) (sig_fused_voice_bus_rows).
+    `pair` = (op, kind2, hertz2, phase2, mix): the filter reads Mix (op 'Mix') or RingMod (op 'RingMod') of the oscillator
+    above and a second one (sig_fused_osc_pair_biquad / sig_fused_voice_pair_bus)."""
+    _gpu(hertz, phase, cutoff, gain, out, bus_gains, workspace, status, *((pair[2], pair[3], pair[4]) if pair else ()))
     _audio(out, 'fused rows out')
     rows = out.shape[0]
     if out.dtype != torch.float32 or rows != block_frames * nblocks:
@@ -557,9 +568,23 @@ def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: in
     cp, cs, crows = _param_rows(cutoff, 'cutoff', voices, nblocks)
     gp, gs, grows = _param_rows(gain, 'gain', voices, nblocks)
     st = status.data_ptr() if status is not None else None
+    pargs = None
+    if pair is not None:
+        op, kind2, hertz2, phase2, mixrow = pair
+        pargs = []
+        for row, name in ((hertz2, 'hertz2'), (phase2, 'phase2'), (mixrow, 'mix')):
+            if row is not None and row.shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+            pargs.extend(_ctrl_row(row, name))
+        head = (OSC_KINDS[kind], OSC_KINDS[kind2], {'Mix': 1, 'RingMod': 2}[op], FILT_TYPES[btype])
     if not bus:
         if out.shape[1] != voices:
             raise NativeError(f'fused rows out has {out.shape[1]} channels for {voices} voices')
+        if pargs is not None:
+            _check(lib().sig_fused_osc_pair_biquad(*head, rate, position, block_frames, nblocks, context, voices, *ptrs, *pargs,
+                                                   cp, cs, crows, gp, gs, grows, out.data_ptr(), out.stride(0), st, _stream(out)),
+                   'sig_fused_osc_pair_biquad')
+            return out
         _check(lib().sig_fused_osc_biquad_rows(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context,
                                                voices, *ptrs, cp, cs, crows, gp, gs, grows, out.data_ptr(), out.stride(0), st,
                                                _stream(out)), 'sig_fused_osc_biquad_rows')
@@ -575,6 +600,11 @@ def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: in
     need = lib().sig_fused_voice_bus_workspace(voices, rows, C)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    if pargs is not None:
+        _check(lib().sig_fused_voice_pair_bus(*head, rate, position, block_frames, nblocks, context, voices, *ptrs, *pargs,
+                                              cp, cs, crows, gp, gs, grows, bp, bld, C, workspace.data_ptr(), out.data_ptr(),
+                                              out.stride(0), st, _stream(out)), 'sig_fused_voice_pair_bus')
+        return out
     _check(lib().sig_fused_voice_bus_rows(OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
                                           *ptrs, cp, cs, crows, gp, gs, grows, bp, bld, C, workspace.data_ptr(), out.data_ptr(),
                                           out.stride(0), st, _stream(out)), 'sig_fused_voice_bus_rows')

@@ -79,6 +79,9 @@ struct FusedArgs {
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
     int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
     int cutoff_rows = 1, gain_rows = 1;      // > 1: one (1,V)|(1,1) parameter row PER BLOCK (sig_fused_*_rows), row b at + b * (stride ? voices : 1)
+    // sig_fused_*_pair: the filter reads Mix(A, B, mix) (pair_op 1) or RingMod(A, B) (pair_op 2) of TWO oscillators
+    int pair_op = 0, kind2 = 0;
+    const double* hertz2 = nullptr; int hs2 = 0; const double* phase2 = nullptr; int ps2 = 0; const double* mixrow = nullptr; int ms = 0;
 };
 
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
@@ -298,9 +301,23 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         int64_t qbase = 0;
         bool q_valid = false;
         if (!FAST) load_hz_ph(hz, ph);
+        // second oscillator of a Mix / RingMod source (ROWS kernels only; its waveform is a wave-uniform run-time switch)
+        const bool paired = ROWS && a.pair_op != 0;
+        double hz2[ROWS ? VPT : 1], ph2[ROWS ? VPT : 1], mx[ROWS ? VPT : 1];
+        if constexpr (ROWS) {
+            if (paired) {
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const int v = (v0 + i < a.voices) ? v0 + i : vc;
+                    hz2[i] = a.hertz2[(int64_t)v * a.hs2];
+                    ph2[i] = a.phase2 ? a.phase2[(int64_t)v * a.ps2] : 0.0;
+                    mx[i] = a.mixrow ? a.mixrow[(int64_t)v * a.ms] : 0.0;
+                }
+            }
+        }
         // exact phase: n/rate (IEEE divide) for 64 rows at a time, one row per lane (osc.py:32)
         auto ensure = [&](int rows) {
-            if (!FAST && (!q_valid || n_cur + rows > qbase + SIG_WAVE)) {     // wave-uniform
+            if ((!FAST || paired) && (!q_valid || n_cur + rows > qbase + SIG_WAVE)) {     // wave-uniform
                 qbase = n_cur;
                 q_lane = (double)(qbase + lane) / a.rate;
                 q_valid = true;
@@ -320,6 +337,23 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
                 for (int i = 0; i < VPT; ++i) {
                     const double t = t_s * hz[i] + ph[i];
                     x[i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+                }
+            }
+            if constexpr (ROWS) {
+                if (paired) {                                                  // x = mix * A + (1 - mix) * B (fx.py:38-40) or A * B (fx.py:45-46)
+                    const double t_s = sig_readlane_f64(q_lane, (int)(n_cur - qbase) + k);
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) {
+                        const double t = t_s * hz2[i] + ph2[i];
+                        double b;
+                        switch (a.kind2) {                                     // wave-uniform
+                            case SIG_OSC_SINE: b = (double)sig_osc::osc_sine_f32(t); break;
+                            case SIG_OSC_SQUARE: b = sig_osc::osc_square(t); break;
+                            case SIG_OSC_SAWTOOTH: b = sig_osc::osc_sawtooth(t); break;
+                            default: b = sig_osc::osc_triangle(t); break;
+                        }
+                        x[i] = (a.pair_op == 1) ? mx[i] * x[i] + (1.0 - mx[i]) * b : x[i] * b;
+                    }
                 }
             }
         };
@@ -1347,16 +1381,27 @@ extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, i
     return gain ? dispatch_kind<true>(osc_kind, a, s) : dispatch_kind<false>(osc_kind, a, s);
 }
 
-extern "C" int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
-                                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
-                                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
-                                         const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
-                                         const double* gain, int32_t gain_stride, int32_t gain_rows,
-                                         float* out, int64_t out_ld, int32_t* status, void* stream)
+namespace {
+struct PairSource { int op, kind2; const double* hertz2; int hs2; const double* phase2; int ps2; const double* mix; int ms; };
+
+bool pair_ok(const PairSource& p) {
+    return p.op == 0 || ((p.op == 1 || p.op == 2) && p.kind2 >= SIG_OSC_SINE && p.kind2 <= SIG_OSC_TRIANGLE && p.hertz2 &&
+                         (p.hs2 | 1) == 1 && (p.ps2 | 1) == 1 && (p.ms | 1) == 1 && (p.op == 2 || p.mix));
+}
+void set_pair(FusedArgs& a, const PairSource& p) {
+    a.pair_op = p.op; a.kind2 = p.kind2; a.hertz2 = p.hertz2; a.hs2 = p.hs2; a.phase2 = p.phase2; a.ps2 = p.ps2;
+    a.mixrow = p.mix; a.ms = p.ms;
+}
+
+int fused_chain_general(int osc_kind, int filt_type, int32_t rate, int64_t position, int32_t block_frames, int32_t nblocks,
+                        int32_t context, int32_t voices, const double* hertz, int32_t hertz_stride, const double* phase,
+                        int32_t phase_stride, const PairSource& pair, const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                        const double* gain, int32_t gain_stride, int32_t gain_rows, float* out, int64_t out_ld, int32_t* status,
+                        void* stream)
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices);
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices && pair_ok(pair));
     SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
     SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
     if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
@@ -1364,7 +1409,80 @@ extern "C" int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t ra
                 hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
                 out, out_ld, 0, status};
     a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
+    set_pair(a, pair);
     return dispatch_rows_kind<0>(osc_kind, a, BusArgs{nullptr, 0, nullptr, 0}, out, out_ld, static_cast<hipStream_t>(stream));
+}
+
+int fused_bus_general(int osc_kind, int filt_type, int32_t rate, int64_t position, int32_t block_frames, int32_t nblocks,
+                      int32_t context, int32_t voices, const double* hertz, int32_t hertz_stride, const double* phase,
+                      int32_t phase_stride, const PairSource& pair, const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                      const double* gain, int32_t gain_stride, int32_t gain_rows, const double* bus_gains, int64_t bus_gains_ld,
+                      int32_t bus_channels, double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
+    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels && pair_ok(pair));
+    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
+    SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
+    SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
+    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
+    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
+                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
+                nullptr, 0, 0, status};
+    a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
+    set_pair(a, pair);
+    BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (bus_channels) {
+        case 1: return dispatch_rows_kind<1>(osc_kind, a, bus, out, out_ld, s);
+        case 2: return dispatch_rows_kind<2>(osc_kind, a, bus, out, out_ld, s);
+    }
+    return (int)hipErrorInvalidValue;                                          // (4-channel buses: the per-node schedule)
+}
+}  // namespace
+
+extern "C" int sig_fused_osc_pair_biquad(int osc_kind, int osc2_kind, int pair_op, int filt_type, int32_t rate, int64_t position,
+                                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                         const double* hertz2, int32_t hertz2_stride, const double* phase2, int32_t phase2_stride,
+                                         const double* mix, int32_t mix_stride,
+                                         const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                         const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                         float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(pair_op == 1 || pair_op == 2);
+    return fused_chain_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                               phase_stride, PairSource{pair_op, osc2_kind, hertz2, hertz2_stride, phase2, phase2_stride, mix, mix_stride},
+                               cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, out, out_ld, status, stream);
+}
+
+extern "C" int sig_fused_voice_pair_bus(int osc_kind, int osc2_kind, int pair_op, int filt_type, int32_t rate, int64_t position,
+                                        int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                        const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                        const double* hertz2, int32_t hertz2_stride, const double* phase2, int32_t phase2_stride,
+                                        const double* mix, int32_t mix_stride,
+                                        const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                        const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                        const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                        double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    SIG_CHECK_ARG(pair_op == 1 || pair_op == 2);
+    return fused_bus_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                             phase_stride, PairSource{pair_op, osc2_kind, hertz2, hertz2_stride, phase2, phase2_stride, mix, mix_stride},
+                             cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, bus_gains, bus_gains_ld, bus_channels,
+                             workspace, out, out_ld, status, stream);
+}
+
+extern "C" int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                         int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                         const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
+                                         const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                         const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                         float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    return fused_chain_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                               phase_stride, PairSource{}, cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, out, out_ld,
+                               status, stream);
 }
 
 extern "C" int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
@@ -1375,24 +1493,9 @@ extern "C" int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rat
                                         const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
                                         double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
 {
-    SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
-    SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels);
-    SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
-    SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
-    SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
-    if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
-    FusedArgs a{filt_type, (double)rate, position, block_frames, nblocks, context, voices,
-                hertz, hertz_stride, phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride,
-                nullptr, 0, 0, status};
-    a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
-    BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (bus_channels) {
-        case 1: return dispatch_rows_kind<1>(osc_kind, a, bus, out, out_ld, s);
-        case 2: return dispatch_rows_kind<2>(osc_kind, a, bus, out, out_ld, s);
-    }
-    return (int)hipErrorInvalidValue;                                          // (4-channel buses: the per-node schedule)
+    return fused_bus_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                             phase_stride, PairSource{}, cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, bus_gains,
+                             bus_gains_ld, bus_channels, workspace, out, out_ld, status, stream);
 }
 
 extern "C" int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const int64_t* position_dev,

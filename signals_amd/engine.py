@@ -809,16 +809,22 @@ class _VoiceChain:
     sig_fused_osc_biquad (chain) or sig_fused_voice_bus (chain + bus); in the latency regime the chain runs as a
     prefix scan and the bus as its own launch, optionally captured into a hipGraph."""
 
-    def __init__(self, batch: _Batch, src, filt, gain_node, bus_node, channels: int, pre_gain=None):
+    def __init__(self, batch: _Batch, src, filt, gain_node, bus_node, channels: int, pre_gain=None, pair=None):
         self.batch, self.src, self.filt, self.gain_node, self.bus_node = batch, src, filt, gain_node, bus_node
         self.pre_gain = pre_gain                                   # a Gain between oscillator and filter, folded into the output gain
+        self.pair = pair                                           # (Mix | RingMod node, second oscillator): the filter reads op(src, second)
+        self.pair_rows = None                                      # (hertz2, phase2, mix) as resolve() found them
         self.channels = channels                                   # voices of the chain
         self.gain_ports = [g.right for g in (pre_gain, gain_node) if g is not None]
         self.ports = [src.hertz, src.phase, filt.cutoff] + self.gain_ports
-        self.involved = [n for n in (src, filt, gain_node, bus_node, pre_gain) if n is not None]
+        self.involved = [n for n in (src, filt, gain_node, bus_node, pre_gain, *(pair or ())) if n is not None]
         self.kind, self.btype = src.kind(), str(filt.type())
         self.modulated = any(not _ctl_const(p) for p in [filt.cutoff] + self.gain_ports)   # per-block parameter rows
-        self.tag = f'{self.kind},{self.btype}{",gain" if self.gain_ports else ""}{",per-block" if self.modulated else ""}'
+        self.general = self.modulated or pair is not None          # the walker's general entry points (sig_fused_*_rows / *_pair)
+        source = self.kind if pair is None else f'{type(pair[0]).__name__}({self.kind},{pair[1].kind()})'
+        self.tag = f'{source},{self.btype}{",gain" if self.gain_ports else ""}{",per-block" if self.modulated else ""}'
+        if pair is not None:
+            self.ports += [pair[1].hertz, pair[1].phase] + ([pair[0].mix] if isinstance(pair[0], fx.Mix) else [])
 
     # ---- matching
     @classmethod
@@ -851,9 +857,17 @@ class _VoiceChain:
             # block-invariant gain in front of it is a factor of the output weight (lowpass_test.sigs: Triangle -> Gain ->
             # LowPass).  The Gain may have other readers: they get its rows from the per-node schedule as usual.
             pre_gain, src = src, src.left.sig
+        pair = None
+        if (pre_gain is None and isinstance(src, (fx.Mix, fx.RingMod)) and src.get_state().enabled and not _modulated(src)
+                and len(src.outputs_with_ports) == 1 and (src, channels) not in batch._memo):
+            # Filter(Mix | RingMod(Osc, Osc)): both oscillators are evaluated per row inside the walker
+            left, right = src.left.sig, src.right.sig
+            if (isinstance(left, osc.Osc) and isinstance(right, osc.Osc) and left is not right and right.get_state().enabled
+                    and len(right.outputs_with_ports) == 1 and _ctl_const(right.hertz) and _ctl_const(right.phase)):
+                pair, src = (src, right), left
         if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
             return None
-        chain = cls(batch, src, filt, gain_node, bus_node, channels, pre_gain)
+        chain = cls(batch, src, filt, gain_node, bus_node, channels, pre_gain, pair)
         controls = chain.resolve()
         if controls is None or not chain.widths_ok(controls):
             return None
@@ -868,6 +882,10 @@ class _VoiceChain:
             return None
         try:
             rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]          # a modulated oscillator is not position-pure
+            if self.pair is not None:
+                op, second = self.pair
+                self.pair_rows = (self.batch._control_const(second.hertz, 'hertz'), self.batch._control_const(second.phase, 'phase'),
+                                  self.batch._control_const(op.mix, 'mix') if isinstance(op, fx.Mix) else None)
             if self.modulated:
                 # cutoff / gain driven by a computed block-rate signal (an LFO sweep, a tremolo): K rows, one per block
                 rows.append(as_control(self.batch._control(self.filt.cutoff, 'cutoff')))
@@ -892,8 +910,15 @@ class _VoiceChain:
     def widths_ok(self, controls) -> bool:
         hertz, phase, cutoff, gain = controls
         v = self.channels
-        return (max(hertz.shape[1], phase.shape[1]) == v and cutoff.shape[1] == v
-                and hertz.shape[1] in (1, v) and phase.shape[1] in (1, v) and (gain is None or gain.shape[1] in (1, v)))
+        source = [hertz, phase] + [t for t in (self.pair_rows or ()) if t is not None]
+        return (max(t.shape[1] for t in source) == v and cutoff.shape[1] == v
+                and all(t.shape[1] in (1, v) for t in source) and (gain is None or gain.shape[1] in (1, v)))
+
+    def pair_arg(self):
+        """the `pair` argument of _native.fused_rows: (op, second kind, hertz2, phase2, mix)"""
+        if self.pair is None:
+            return None
+        return (type(self.pair[0]).__name__, self.pair[1].kind(), *self.pair_rows)
 
     def cycles_per_frame_bound(self) -> tuple[float, float]:
         """(max |hertz| / rate, max |phase|) over the chain's voices, from the host arrays behind the Fixed controls
@@ -967,9 +992,10 @@ class _VoiceChain:
         name = f'fused_osc_biquad[{self.tag}]'
 
         def run(position, ctl, out):
-            if self.modulated:
+            if self.general:
                 return o._launch(name, lambda: _native.fused_rows(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
-                                                                  ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
+                                                                  ctl[0], ctl[1], ctl[2], ctl[3], out, status=status,
+                                                                  pair=self.pair_arg()),
                                  units=rows * v)
             return o._launch(name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
                                                                     ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
@@ -996,8 +1022,8 @@ class _VoiceChain:
     def launch_mix(self, mix_node, controls) -> torch.Tensor:
         b, o = self.batch, self.batch.owner
         N, K, v = b.N, b.K, self.channels
-        if self.modulated:
-            return None                                             # per-block rows: the chain runs fused, the matrix as its own launch
+        if self.general:
+            return None                                             # per-block rows / two oscillators: the chain runs fused, the matrix as its own launch
         out = torch.empty((N * K, v), dtype=AUDIO_DTYPE, device=runtime.device())
         matrix, status = mix_node.resident_matrix(), o._status_word(self.filt)
         return o._launch(f'fused_osc_biquad_mix[{self.tag}]',
@@ -1018,14 +1044,15 @@ class _VoiceChain:
         need = _native.lib().sig_fused_voice_bus_workspace(v, rows, bus_c) // 8
         if o._workspace is None or o._workspace.numel() < need:
             o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=dev)
-        if self.modulated:
+        if self.general:
             if bus_c not in (1, 2):
                 return None
             out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
             return o._launch(f'fused_voice_bus[{self.tag}]',
                              lambda: _native.fused_rows(self.kind, self.btype, rate, b.pos, N, K, CONTEXT, v, controls[0], controls[1],
                                                         controls[2], controls[3], out, bus_gains=pan, bus=True,
-                                                        workspace=o._workspace, status=status), units=rows * v)
+                                                        workspace=o._workspace, status=status, pair=self.pair_arg()),
+                             units=rows * v)
         # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs as a
         # time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
         small = v * K <= o.scan_max_chains and CONTEXT + N <= SCAN_MAX_ROWS

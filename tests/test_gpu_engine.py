@@ -809,3 +809,41 @@ def test_lfo_swept_cutoff_and_tremolo_run_in_the_fused_chain(golden):
                 assert maxerr(got, f32(ref)) < 1e-6, (kind, bus, tremolo)
                 eager = stream(build(kind, bus, tremolo), 4096, N, 9, 1 if bus else V)
                 assert maxerr(got, eager) < 1e-6, (kind, bus, tremolo)
+
+
+def test_two_oscillators_through_mix_or_ringmod_in_front_of_the_filter(golden):
+    """Filter(Mix(Osc, Osc, m)) and Filter(RingMod(Osc, Osc)) (fx.py:35-46): both oscillators are evaluated per row inside
+    the walker (sig_fused_osc_pair_biquad / sig_fused_voice_pair_bus) -- one launch instead of osc, osc, element-wise,
+    filter [, gain, bus]; every waveform as the second oscillator, a Sine first oscillator on its incremental phase"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    V, N, K = 32, 256, 4
+    hz, ph, cut, gain = g['c2/hertz'], g['c2/phase'], g['c2/cutoff'], g['c2/gain']
+    rng = np.random.default_rng(77)
+    hz2, ph2, m = rng.uniform(30, 900, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(0, 1, (1, V))
+    for op in ('Mix', 'RingMod'):
+        for kind_a, kind_b in (('Sine', 'Sawtooth'), ('Triangle', 'Sine'), ('Square', 'Triangle'), ('Sawtooth', 'Square')):
+            for bus in (False, True):
+                e = getattr(fx, op)(); e.left = mkosc(kind_a, hz, ph); e.right = mkosc(kind_b, hz2, ph2)
+                if op == 'Mix':
+                    e.mix = fix(m)
+                f = fx.LowPass(); f.input = e; f.cutoff = fix(cut)
+                top = fx.Gain(); top.left = f; top.right = fix(gain)
+                if bus:
+                    b = ext.SumBus(); b.input = top
+                    top = b
+                timer = KernelTimer()
+                r = BatchRenderer(top, 1 if bus else V, RATE, timer=timer)
+                got = np.concatenate([r.render(300, N, K).cpu().numpy(), r.render(300 + N * K, N, 2).cpu().numpy()])
+                torch.cuda.synchronize()
+                names = set(timer.summary())
+                want_name = f'{"fused_voice_bus" if bus else "fused_osc_biquad"}[{op}({kind_a},{kind_b}),lp,gain]'
+                assert names == {want_name}, names
+                src = R.Binary(op, R.Osc(kind_a, R.Fixed(hz), R.Fixed(ph)), R.Osc(kind_b, R.Fixed(hz2), R.Fixed(ph2)),
+                               R.Fixed(m) if op == 'Mix' else None)
+                node = R.Binary('Gain', R.Filter('lp', src, R.Fixed(cut)), R.Fixed(gain))
+                ref = np.concatenate([R.render(node, 300 + i * N, N, V, RATE) for i in range(K + 2)])
+                ref = R.sum_bus(ref) if bus else ref
+                assert maxerr(got, f32(ref)) < 1e-6, (op, kind_a, kind_b, bus)
