@@ -184,3 +184,19 @@ def test_bad_cutoff_in_either_filter_is_reported():
     r2.render(0, N, 2)
     with pytest.raises(ValueError):
         runtime.check_status()
+
+
+def test_block_sizes_the_cascade_kernel_does_not_take_fall_back_to_the_older_schedule():
+    """N must be a whole number of row groups (16 / bus channels) and > 100: otherwise the engine keeps its two-launch
+    schedule (fused Saw + LowPass, then filter + envelope + bus), same values within the float32 roundings between them"""
+    from signals_amd.engine import KernelTimer
+    V, K = 24, 3
+    p = params(V, 31)
+    for N in (1000, 250):
+        timer = KernelTimer()
+        got = fused(graph(p), 1, timer).render(0, N, K).cpu().numpy()
+        torch.cuda.synchronize()
+        names = set(timer.summary())
+        assert not any(n.startswith('fused_cascade_bus') for n in names) and any(n.startswith('biquad_bus') for n in names), names
+        ref = oracle_stream(p, 0, N, K, V)
+        assert maxerr(got, f32(ref)) < 2e-6 * max(1.0, np.abs(ref).max()), N
