@@ -559,8 +559,9 @@ def main():
                                    f'engine schedule = {describe(not args.materialised)}',
                        'voices_per_gpu': V, 'block_frames': N, 'blocks_per_step': K, 'start_position': args.position,
                        'parallelism': f'voices sharded {V}/GPU x{world}; '
-                                      + (f'torch.distributed backend {backend} (RCCL), {world} ranks: one async reduce of the '
-                                         f'stereo bus to rank 0 per batch' if backend else 'single process, no collective'),
+                                      + (f'torch.distributed backend {backend}{" (RCCL over xGMI)" if backend == "nccl" else ""}, '
+                                         f'{world} ranks: one async reduce of the stereo bus to rank 0 per batch'
+                                         if backend else 'single process, no collective'),
                        'rccl_ranks': world if backend == 'nccl' else 0, 'dist_backend': backend},
         }
         for k in ('roofline', 'kernels', 'sustained'):
