@@ -817,7 +817,6 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     // variants' registers had to be shuffled into one layout at every merge).  Phase of variant M runs until every slot
     // >= the next smaller variant has dropped.
     using Variants = SteadyVariants<VPT>;
-    const int n_groups = (a.N / R) * R;                                        // rows of a block done in whole groups
 
     for (int bi = 0; bi < nb; ++bi) {
         // homogeneous state at the block's first row; only the launch's very first block can have a short context
@@ -846,7 +845,6 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
             ++done;
             stage.advance();
         };
-        const bool ragged = stage.staged != 0;                                 // (the previous block left a partly filled tile)
         while (stage.staged != 0 && done < a.N) single();
         // phases; after single rows `done` is not a multiple of R, the groups simply start there
         const int last_group_row = done + ((a.N - done) / R) * R;
@@ -874,7 +872,6 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
                 if (drop_at[i] <= done) { z0h[i] = 0.0; z1h[i] = 0.0; }        // dropped slots were not advanced: exact zeros
             while (done < a.N) single();
         }
-        (void)ragged; (void)n_groups;
     }
     if (have) folded.finish(pend, pend_row, R);
     if (stage.staged) stage.now();
