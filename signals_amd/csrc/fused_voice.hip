@@ -643,11 +643,10 @@ constexpr int kNeverDrops = 0x3fffffff;
 // the row-group variants of fused_steady_bus_kernel: "the first M of the lane's VPT voice slots still carry their
 // homogeneous part", largest first
 template <int VPT> struct SteadyVariants {
-    static constexpr int count = (VPT == 16) ? 9 : (VPT == 8) ? 7 : (VPT == 4) ? 4 : (VPT == 2) ? 3 : 2;
-    static constexpr int at(int k) {
-        constexpr int v16[9] = {16, 12, 8, 6, 4, 3, 2, 1, 0}, v8[7] = {8, 6, 4, 3, 2, 1, 0}, v4[4] = {4, 2, 1, 0},
-                      v2[3] = {2, 1, 0}, v1[2] = {1, 0};
-        return (VPT == 16) ? v16[k] : (VPT == 8) ? v8[k] : (VPT == 4) ? v4[k] : (VPT == 2) ? v2[k] : v1[k];
+    static constexpr int count = (VPT >= 8) ? 7 : (VPT == 4) ? 4 : (VPT == 2) ? 3 : 2;
+    static constexpr int at(int k) {                   // (16 voices per lane: registers for 8 live slots, like 8 per lane)
+        constexpr int v8[7] = {8, 6, 4, 3, 2, 1, 0}, v4[4] = {4, 2, 1, 0}, v2[3] = {2, 1, 0}, v1[2] = {1, 0};
+        return (VPT >= 8) ? v8[k] : (VPT == 4) ? v4[k] : (VPT == 2) ? v2[k] : v1[k];
     }
 };
 
@@ -658,7 +657,7 @@ template <int VPT> struct SteadyVariants {
 #define SIG_STEADY_OCC8 1
 #endif
 #ifndef SIG_STEADY_AUTO16
-#define SIG_STEADY_AUTO16 0              // 16 voices per lane spill (512 registers + scratch): tuning hook only
+#define SIG_STEADY_AUTO16 0              // 16 voices per lane (live slots capped at 8): 512 registers, AGPR copies and scratch -- 266 us vs 205 with 8: tuning hook only
 #endif
 #ifndef SIG_STEADY_OCC16
 #define SIG_STEADY_OCC16 1
@@ -670,6 +669,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<V
 void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     constexpr int R = kPairs / C;          // rows per flush
+    constexpr int LC = SteadyVariants<VPT>::at(0);     // voice slots that can carry a homogeneous part (all of them up to 8 per lane)
     static_assert(R % 2 == 0, "the two-term recurrence rotates two registers per voice: row groups are even");
     __shared__ double lds[4][kPairs * kTileStride];
     const int lane = threadIdx.x & 63;
@@ -692,7 +692,7 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     // per voice: the filter (na1, na2), the oscillator step k = 2 cos(theta), the steady-state output at rows p0 - 1
     // and p0 (ya, yb), the bus weights; per voice SLOT (wave-uniform): rows from a cold start after which the
     // homogeneous part is dropped
-    double na1[VPT], na2[VPT], k2c[VPT], ya[VPT], yb[VPT], wt[C][VPT];
+    double na1[LC], na2[LC], k2c[VPT], ya[VPT], yb[VPT], wt[C][VPT];
     int nd_total[VPT];
     const double q_first = (double)p0 / a.rate;
 #pragma unroll
@@ -700,10 +700,12 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
         const bool live = v0 + i < a.voices;
         const int v = live ? v0 + i : vc;                                      // dead voices shadow a live one ...
         auto cst = [&](int k) { return sc[(int64_t)k * a.voices + v]; };
-        na1[i] = cst(SC_NA1); na2[i] = cst(SC_NA2); k2c[i] = cst(SC_K2C);
+        const double na1_i = cst(SC_NA1);
+        if (i < LC) { na1[i < LC ? i : 0] = na1_i; na2[i < LC ? i : 0] = cst(SC_NA2); }
+        k2c[i] = cst(SC_K2C);
         // the design is checked where the constants are made (steady_prep_kernel); a caller that keeps them across
         // calls skips that launch, so every launch that USES a rejected design (NaN coefficients) reports it again
-        if (live && na1[i] != na1[i] && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+        if (live && na1_i != na1_i && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
         const double scale = cst(SC_SCALE);
 #pragma unroll
         for (int ch = 0; ch < C; ++ch)                                         // ... with weight exactly 0 on the bus
@@ -725,7 +727,20 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     double* dstp = bus.partials + (int64_t)vt * bus.rows * C;                  // [tile][row][c]
     sig_bus::PipelinedTile<C> stage(tile, lane, dstp, b_first * a.N);
 
-    double z0h[VPT], z1h[VPT];
+    // 16 voices per lane: only the first 8 slots have registers for a homogeneous part; the caller vouched (consts_ready
+    // bit 1) that the others have none at any block start of this launch -- checked here, a wave it does not hold for takes
+    // the plain fallback (correct, slow)
+    if constexpr (LC < VPT) {
+        const int c_min = (b_first == 0 && a.position < (int64_t)a.ctx) ? (int)a.position : a.ctx;
+        bool capped = true;
+#pragma unroll
+        for (int i = LC; i < VPT; ++i) capped &= nd_total[i] <= c_min;
+        if (!capped) {                                                         // wave-uniform
+            steady_fallback_span<VPT, C>(a, bus, tile, lane, vt, b_first, nb, v0);
+            return;
+        }
+    }
+    double z0h[LC], z1h[LC];
     // One row of every voice; the first M slots carry their homogeneous part, the others have dropped it.  The row's C
     // sums over the lane's voices go to `sums` (registers of the group being built, or the LDS slot of the single-row
     // form).  The two-term recurrence runs IN PLACE on two registers per voice: on an even row yb is the sample and ya
@@ -740,10 +755,11 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
             if (ODD) yb[i] = fma(k2c[i], ya[i], -yb[i]);
             else ya[i] = fma(k2c[i], yb[i], -ya[i]);
             if (i < M) {
-                y[i] = ys + z0h[i];
-                const double yh = z0h[i];
-                z0h[i] = fma(na1[i], yh, z1h[i]);
-                z1h[i] = na2[i] * yh;
+                const int j = i < LC ? i : 0;                                  // (M <= LC: always i itself)
+                y[i] = ys + z0h[j];
+                const double yh = z0h[j];
+                z0h[j] = fma(na1[j], yh, z1h[j]);
+                z1h[j] = na2[j] * yh;
             } else {
                 y[i] = ys;
             }
@@ -776,12 +792,13 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
             y1[i] = ya[i];
             yb[i] = fma(k2c[i], ya[i], -yb[i]);
             if (i < M) {
-                const double h0 = z0h[i];
+                const int j = i < LC ? i : 0;                                  // (M <= LC: always i itself)
+                const double h0 = z0h[j];
                 y0[i] += h0;
-                const double h1 = fma(na1[i], h0, z1h[i]);
+                const double h1 = fma(na1[j], h0, z1h[j]);
                 y1[i] += h1;
-                z0h[i] = fma(na1[i], h1, na2[i] * h0);
-                z1h[i] = na2[i] * h1;
+                z0h[j] = fma(na1[j], h1, na2[j] * h0);
+                z1h[j] = na2[j] * h1;
             }
         }
         double acc0[C], acc1[C];
@@ -823,9 +840,9 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
         const bool first = (b_first + bi == 0);
         const int tk = first ? SC_T0 : SC_T;
         const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
-        int drop_at[VPT];                                                      // row of the block from which slot i is dropped
+        int drop_at[LC];                                                       // row of the block from which slot i is dropped
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
+        for (int i = 0; i < LC; ++i) {
             drop_at[i] = (nd_total[i] > c) ? nd_total[i] - c : 0;              // wave-uniform
             if (drop_at[i] > 0) {
                 const int v = (v0 + i < a.voices) ? v0 + i : vc;
@@ -839,7 +856,7 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
         }
         int done = 0;
         auto single = [&]() {                                                  // (dropped slots carry zeros: the full row is exact)
-            row(stage.slot, kTileStride, std::integral_constant<int, VPT>{}, std::false_type{});
+            row(stage.slot, kTileStride, std::integral_constant<int, LC>{}, std::false_type{});
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { const double t = ya[i]; ya[i] = yb[i]; yb[i] = t; }   // back to (previous, current)
             ++done;
@@ -854,7 +871,7 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
             constexpr int lower = (K + 1 < Variants::count) ? Variants::at(K + 1) : 0;
             int until = 0;                                                     // first row at which every slot >= lower has dropped
 #pragma unroll
-            for (int i = lower; i < VPT; ++i) until = (i < M && drop_at[i] > until) ? drop_at[i] : until;
+            for (int i = lower; i < LC; ++i) until = (i < M && drop_at[i] > until) ? drop_at[i] : until;
             if (M == 0) until = a.N;
             until = (until < last_group_row) ? until : last_group_row;
             while (done < until) {                                             // (a group that starts before `until` runs whole)
@@ -868,7 +885,7 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
         if (done < a.N) {                                                      // rows left over: one at a time, after the pending flush
             if (have) { folded.finish(pend, pend_row, R); have = false; }
 #pragma unroll
-            for (int i = 0; i < VPT; ++i)
+            for (int i = 0; i < LC; ++i)
                 if (drop_at[i] <= done) { z0h[i] = 0.0; z1h[i] = 0.0; }        // dropped slots were not advanced: exact zeros
             while (done < a.N) single();
         }

@@ -54,7 +54,8 @@ def steady():
     consts = torch.empty(_native.lib().sig_fused_voice_consts_size(V) // 8, dtype=torch.float64, device='cuda')
 
     def run(perm, cut, label):
-        hz, ph, g, pan, c = (dev(p[k][:, perm]) for k in ('hertz', 'phase', 'gain', 'pan')) + (dev(cut),)
+        hz, ph, g, pan = (dev(p[k][:, perm]) for k in ('hertz', 'phase', 'gain', 'pan'))
+        c = dev(cut)
         call = lambda ready: _native.fused_voice_bus('Sine', 'lp', 48000, N * K, N, K, 100, V, hz, ph, c, g, pan, out, workspace=ws,
                                                      consts=consts, consts_ready=ready)
         call(False)
@@ -66,7 +67,7 @@ def steady():
     for m in range(1, 8):
         cut = np.full((1, V), 6000.0).reshape(2, 64, 8); cut[:, :, :m] = 300.0
         run(ident, cut.reshape(1, V), f'{m} slots live')
-    for vpt in (8, 4):
+    for vpt in (16, 8, 4):
         perm = ordered(p['cutoff'].reshape(-1), V, vpt)
         for span in (8, 4, 2, 1):
             _native.set_fused_tuning(vpt, span, 1, 0)
