@@ -294,7 +294,7 @@ def test_closed_form_vs_walker_over_random_parameter_draws():
         pos = int(rng.choice([0, 1, 99, 100, 4096, 48000 * 600]))
         btype = str(rng.choice(['lp', 'hp']))
         C = int(rng.choice([1, 2, 4]))
-        vpt, span = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 4, 8]))
+        vpt, span = int(rng.choice([1, 2, 4, 8, 16])), int(rng.choice([1, 2, 4, 8]))     # (16: the steady kernel only; the walker clamps to 4)
         p = dict(hertz=np.exp(rng.uniform(np.log(8.0), np.log(11900.0), (1, V))) * rng.choice([-1.0, 1.0], (1, V)),
                  phase=rng.uniform(-2, 2, (1, V)), cutoff=np.exp(rng.uniform(np.log(20.0), np.log(23000.0), (1, V))),
                  gain=rng.uniform(0.1, 1, (1, V)) / np.sqrt(V), pan=rng.uniform(-1, 1, (4, V)))
