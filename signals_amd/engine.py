@@ -165,6 +165,7 @@ class BatchRenderer:
         self._stream_end: int | None = None
         self._prev_block_frames: int | None = None         # N of the previous render (where a fused cascade's history block starts)
         self._virtual_history = False                      # the previous batch kept its filter history implicit (no tails needed)
+        self._cascade_stream = False                       # ... and this batch continues it
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -192,6 +193,7 @@ class BatchRenderer:
         continuing = self._stream_end == position and (bool(self._tails) or self._virtual_history)
         if not continuing:
             self._tails.clear()
+        self._cascade_stream = continuing and self._virtual_history    # the previous batch ran the fused cascade
         self._virtual_history = False                      # set again by a launch that keeps its history implicit (fused cascade)
         batch = _Batch(self, position, block_frames, nblocks, continuing)
         out = batch.buffer(self.node, self.channels, 0)
@@ -598,7 +600,12 @@ class _Batch:
             return None
         if self.pos == 0:
             history = 0
-        elif self.continuing and o._prev_block_frames and self.pos - o._prev_block_frames >= 0:
+        elif self.continuing:
+            # the block in front of this batch: the kernel re-walks it from where the reference cold-started it.  Only if
+            # the previous render kept its history implicit as well (a per-node batch left tails of rounded float32 rows)
+            # and that block covers the outer filter's context
+            if not o._cascade_stream or not o._prev_block_frames or o._prev_block_frames < min(CONTEXT, self.pos):
+                return None
             history = self.pos - o._prev_block_frames
         else:
             history = self.pos - min(CONTEXT, self.pos)

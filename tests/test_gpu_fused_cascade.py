@@ -200,3 +200,30 @@ def test_block_sizes_the_cascade_kernel_does_not_take_fall_back_to_the_older_sch
         assert not any(n.startswith('fused_cascade_bus') for n in names) and any(n.startswith('biquad_bus') for n in names), names
         ref = oracle_stream(p, 0, N, K, V)
         assert maxerr(got, f32(ref)) < 2e-6 * max(1.0, np.abs(ref).max()), N
+
+
+def test_a_stream_may_switch_between_the_per_node_schedule_and_the_cascade_kernel():
+    """the cascade kernel re-walks the previous block itself, the per-node schedule keeps rounded float32 tails: a batch
+    that continues a per-node batch stays per-node (its history is those tails), a fresh stream or a stream of cascade
+    batches uses the kernel; every combination renders the oracle's sequential stream"""
+    from signals_amd.engine import KernelTimer
+    V, N = 24, 256
+    p = params(V, 41)
+    ref = oracle_stream(p, 0, N, 6, V)
+    scale = max(1.0, np.abs(ref).max())
+    timer = KernelTimer()
+    r = fused(graph(p), 1, timer)
+    r.fuse_cascade = False
+    a = r.render(0, N, 2).cpu().numpy()                       # per-node: fused Saw + LowPass, then filter + envelope + bus
+    r.fuse_cascade = True
+    b = r.render(2 * N, N, 2).cpu().numpy()                   # continues the per-node batch: tails
+    torch.cuda.synchronize()
+    assert not any(n.startswith('fused_cascade_bus') for n in timer.summary())
+    r.reset()
+    c = r.render(4 * N, N, 2).cpu().numpy()                   # a FRESH start mid-stream: the cascade kernel, fresh-graph history
+    torch.cuda.synchronize()
+    assert any(n.startswith('fused_cascade_bus') for n in timer.summary())
+    assert maxerr(np.concatenate([a, b]), f32(ref[:4 * N])) < 2e-6 * scale
+    from oracle import chain_ref as R
+    node, _ = oracle(p)
+    assert maxerr(c, f32(R.sum_bus(R.render_stream(node, 4 * N, N, 2, V)))) < 2e-6 * scale
