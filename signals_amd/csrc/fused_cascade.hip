@@ -8,20 +8,27 @@
 // block b at frame p:
 //     inner_b  = Filter1 from zero state over osc rows [p - 100, p + N),         kept rows [p, p + N)
 //     outer_b  = Filter2 from zero state over [inner_{b-1}'s last 100 rows | inner_b], kept rows [p, p + N)
-// A lane owns `span` consecutive blocks of its voices and walks time once.  In the last 100 rows of block b it runs four
-// recurrences per voice on the samples it has at hand: inner_b and outer_b (the output), inner_{b+1}'s warm-up on the
-// oscillator sample, outer_{b+1}'s warm-up on inner_b's output; at the block boundary the warm-up chains become the
-// output chains.  The first block of a span needs inner_{b-1}'s last 100 rows: the lane first walks that whole
-// HISTORY BLOCK (oscillator + inner filter only, cold-started where the reference cold-started it).  For the launch's
-// very first block the caller says where the history block starts (`first_history_start`): position - N_previous on a
-// continuing stream, position - min(100, position) on a fresh graph (the reference then renders [p - 100, p) as a
-// block of its own), position itself at frame 0 (no history).
+// A lane owns `span` consecutive blocks of its voices and walks time once with ONE pair of recurrences per voice (inner,
+// outer).  The cold starts come from linearity: two solutions of  z' = A z + B x  over the same input differ by a
+// homogeneous solution, so the chain cold-started at row r is the running chain minus what the running chain's state at
+// r has become,
+//     z_cold(p) = z_run(p) - A^(p - r) z_run(r),         A = [[-a1, 1], [-a2, 0]]  (b0-normalised DF2T)
+// -- for the inner filter of block b+1 (input: the oscillator) and for its outer filter (input over the 100 context
+// rows: inner_b's output, which is what the running outer chain consumes there) alike.  So a lane keeps a copy of both
+// states as they stand 100 rows before a block's end and, at the boundary, subtracts A^100 times the copy (a 2x2 power
+// by squaring per voice and filter: 80 operations per block instead of two more recurrences over 100 rows).  The first
+// block of a span needs inner_{b-1}'s last 100 rows: the lane first walks that whole HISTORY BLOCK (oscillator + inner
+// filter, cold-started where the reference cold-started it; the outer filter joins, from zero state, for the last 100
+// rows).  For the launch's very first block the caller says where the history block starts (`first_history_start`):
+// position - N_previous on a continuing stream, position - min(100, position) on a fresh graph (the reference then
+// renders [p - 100, p) as a block of its own), position itself at frame 0 (no history).
 //
 // Arithmetic as in fused_voice.hip: exact per-row phase t = n / rate * hertz + phase (n / rate for 64 rows at a time, one
-// row per lane, broadcast by v_readlane), b0-normalised DF2T (4 FMAs per filter row, both b0 folded into the output
-// weight), envelope as the voice's current linear stage (sig_adsr.h: Segment), bus sums folded across lanes by
-// sig_bus::FoldedGroup.  The inner filter's output reaches the outer filter in f64 (the per-node path rounds it to
-// f32 on the way): closer to the f64 reference, 1e-6 parity asserted against the oracle in the tests.
+// row per lane, broadcast by v_readlane), b0-normalised DF2T (4 operations per filter row, both b0 folded into the output
+// weight), envelope as the voice's current linear stage (sig_adsr.h: Segment) folded with the bus weight into one fma
+// per (voice, channel, row), bus sums folded across lanes by sig_bus::FoldedGroup.  The inner filter's output reaches
+// the outer filter in f64 (the per-node path rounds it to f32 on the way): closer to the f64 reference, 1e-6 parity
+// asserted against the oracle in the tests.
 #include <type_traits>
 
 #include "sig_adsr.h"
@@ -45,6 +52,26 @@ struct CascadeArgs {
 
 constexpr int kFoldTileDoubles = kPairs * sig_bus::kFoldStride;
 
+// A^e for A = [[na1, 1], [na2, 0]], by squaring (e wave-uniform, >= 0)
+struct Mat2 { double a, b, c, d; };
+__device__ __forceinline__ Mat2 mul(const Mat2& x, const Mat2& y) {
+    return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
+}
+__device__ __forceinline__ Mat2 transition_power(double na1, double na2, int e) {
+    Mat2 r{1.0, 0.0, 0.0, 1.0}, base{na1, 1.0, na2, 0.0};
+    for (; e > 0; e >>= 1) {
+        if (e & 1) r = mul(r, base);
+        if (e > 1) base = mul(base, base);
+    }
+    return r;
+}
+// z <- z - A^e s : the chain cold-started e rows ago, from the running chain z and its state s of e rows ago
+__device__ __forceinline__ void restart(double na1, double na2, int e, double s0, double s1, double& z0, double& z1) {
+    const Mat2 m = transition_power(na1, na2, e);
+    z0 -= fma(m.a, s0, m.b * s1);
+    z1 -= fma(m.c, s0, m.d * s1);
+}
+
 template <int KIND, int VPT, bool ENV, int C>
 __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_env::AdsrRows env)
 {
@@ -62,8 +89,9 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
 
     const double s2a = (a.type1 == SIG_FILT_LOWPASS) ? 2.0 : -2.0, s2b = (a.type2 == SIG_FILT_LOWPASS) ? 2.0 : -2.0;   // b1 / b0
     double hz[VPT], ph[VPT], a1a[VPT], a2a[VPT], a1b[VPT], a2b[VPT], wt[C][VPT];
-    double za0[VPT], za1[VPT], zb0[VPT], zb1[VPT];                             // the output chains: inner, outer
-    sig_env::Segment seg[ENV ? VPT : 1];
+    double za0[VPT], za1[VPT], zb0[VPT], zb1[VPT];                             // the running chains: inner, outer
+    double sa0[VPT], sa1[VPT], sb0[VPT], sb1[VPT];                             // their states `ctx` rows before the block's end
+    double seg_end[ENV ? VPT : 1], sw[C][ENV ? VPT : 1], lw[C][ENV ? VPT : 1]; // the envelope's current stage, times the weights
     bool ok = true, any_live = false;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -80,7 +108,8 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) wt[ch][i] = live ? (a.pan ? a.pan[ch * a.pan_ld + v] * scale : scale) : 0.0;
         za0[i] = za1[i] = zb0[i] = zb1[i] = 0.0;
-        if (ENV) seg[i].end = -1.0;                                            // derived at the first output row
+        sa0[i] = sa1[i] = sb0[i] = sb1[i] = 0.0;
+        if (ENV) seg_end[i] = -1.0;                                            // derived at the first output row
     }
     if (!ok && any_live && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 
@@ -97,7 +126,7 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     };
     auto osc = [&](double q, int i) {
         const double t = q * hz[i] + ph[i];
-        return (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+        return (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave_fused<KIND>(t);
     };
     // one step of the b0-normalised DF2T of [1, s2, 1] / [1, -na1, -na2]
     auto biquad = [](double x, double s2, double na1, double na2, double& z0, double& z1) {
@@ -110,11 +139,8 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     const int64_t p_first = a.position + b_first * a.N;                        // first frame of the span's first block
     const int c = (int)((p_first < (int64_t)a.ctx) ? p_first : (int64_t)a.ctx);   // BlockLoc.before: min(ctx, position)
 
-    // ---- history: inner filter over the block in front of the span, cold-started where the reference cold-started it;
-    // over its last c rows the span's first block warms up: inner (wa) on the oscillator, outer (wb) on the history's output
-    double wa0[VPT], wa1[VPT], wb0[VPT], wb1[VPT];
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) wa0[i] = wa1[i] = wb0[i] = wb1[i] = 0.0;
+    // ---- history: the inner filter over the block in front of the span, cold-started where the reference cold-started
+    // it; over its last c rows the outer filter of the span's first block warms up on it from zero state
     {
         const int64_t h0 = (b_first == 0) ? a.first_history_start : p_first - a.N;
         const int ch = (int)((h0 < (int64_t)a.ctx) ? h0 : (int64_t)a.ctx);
@@ -134,19 +160,17 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
 #pragma unroll
             for (int i = 0; i < VPT; ++i) biquad(osc(q, i), s2a, a1a[i], a2a[i], za0[i], za1[i]);
         }
-        for (; n < p_first; ++n) {                                             // + the first block's two warm-up chains
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { sa0[i] = za0[i]; sa1[i] = za1[i]; }
+        for (; n < p_first; ++n) {
             ensure(n, 1);
             const double q = sig_readlane_f64(q_lane, (int)(n - qbase));
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) {
-                const double x = osc(q, i);
-                const double y1 = biquad(x, s2a, a1a[i], a2a[i], za0[i], za1[i]);
-                biquad(x, s2a, a1a[i], a2a[i], wa0[i], wa1[i]);
-                biquad(y1, s2b, a1b[i], a2b[i], wb0[i], wb1[i]);
-            }
+            for (int i = 0; i < VPT; ++i)
+                biquad(biquad(osc(q, i), s2a, a1a[i], a2a[i], za0[i], za1[i]), s2b, a1b[i], a2b[i], zb0[i], zb1[i]);
         }
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) { za0[i] = wa0[i]; za1[i] = wa1[i]; zb0[i] = wb0[i]; zb1[i] = wb1[i]; }
+        for (int i = 0; i < VPT; ++i) restart(a1a[i], a2a[i], c, sa0[i], sa1[i], za0[i], za1[i]);   // the first block's inner filter
     }
 
     double* dstp = a.partials + (int64_t)vt * a.rows * C;                      // [tile][row][c]
@@ -155,40 +179,38 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     int64_t pend_row = 0, out_row = b_first * a.N;
     bool have = false;
 
-    // One group of R output rows starting at frame n.  WARM: the next block's two warm-up chains run on the rows at and
-    // after `warm_from` (rows before it feed them zeros, which leaves a zero state zero).  CHECKED: some voice's envelope
-    // stage ends inside the group, so every row re-derives the stages that have ended (rare: five boundaries per voice).
-    auto group = [&](int64_t n, int64_t warm_from, auto warm_tag, auto checked_tag) {
-        constexpr bool WARM = decltype(warm_tag)::value, CHECKED = decltype(checked_tag)::value;
+    // One group of R output rows starting at frame n.  SNAP: the states are copied before row `snap_at` of the group (the
+    // block's row N - ctx).  CHECKED: some voice's envelope stage ends inside the group, so every row re-derives the
+    // stages that have ended (rare: five boundaries per voice).
+    auto group = [&](int64_t n, int snap_at, auto snap_tag, auto checked_tag) {
+        constexpr bool SNAP = decltype(snap_tag)::value, CHECKED = decltype(checked_tag)::value;
         ensure(n, R);
         double acc[kPairs];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double q = sig_readlane_f64(q_lane, (int)(n - qbase) + k);
-            const double mask = (WARM && n + k >= warm_from) ? 1.0 : 0.0;       // wave-uniform
+            if (SNAP && k == snap_at) {                                        // wave-uniform
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) { sa0[i] = za0[i]; sa1[i] = za1[i]; sb0[i] = zb0[i]; sb1[i] = zb1[i]; }
+            }
             double y[VPT];
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
-                const double x = osc(q, i);
-                const double y1 = biquad(x, s2a, a1a[i], a2a[i], za0[i], za1[i]);
-                y[i] = biquad(y1, s2b, a1b[i], a2b[i], zb0[i], zb1[i]);
-                if (WARM) {
-                    biquad(x * mask, s2a, a1a[i], a2a[i], wa0[i], wa1[i]);
-                    biquad(y1 * mask, s2b, a1b[i], a2b[i], wb0[i], wb1[i]);
-                }
-                if (ENV) {
-                    if (CHECKED && !(q < seg[i].end)) {                        // a stage boundary: per lane
-                        const int v = (v0 + i < a.voices) ? v0 + i : vc;
-                        seg[i] = sig_env::segment_at(sig_env::load_voice(env, v), q);
-                    }
-                    y[i] *= fma(seg[i].slope, q - seg[i].t0, seg[i].l0);
+                y[i] = biquad(biquad(osc(q, i), s2a, a1a[i], a2a[i], za0[i], za1[i]), s2b, a1b[i], a2b[i], zb0[i], zb1[i]);
+                if (ENV && CHECKED && !(q < seg_end[i])) {                     // a stage boundary: per lane
+                    const int v = (v0 + i < a.voices) ? v0 + i : vc;
+                    const sig_env::Segment s = sig_env::segment_at(sig_env::load_voice(env, v), q);
+                    seg_end[i] = s.end;
+                    const double l = fma(-s.slope, s.t0, s.l0);                // level(t) = l + slope * t within the stage
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) { sw[ch][i] = s.slope * wt[ch][i]; lw[ch][i] = l * wt[ch][i]; }
                 }
             }
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
                 double s = 0.0;
 #pragma unroll
-                for (int i = 0; i < VPT; ++i) s = fma(wt[ch][i], y[i], s);
+                for (int i = 0; i < VPT; ++i) s = fma(ENV ? fma(sw[ch][i], q, lw[ch][i]) : wt[ch][i], y[i], s);
                 acc[k * C + ch] = s;
             }
 #pragma unroll
@@ -200,33 +222,36 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
         folded.issue(pend);
         pend_row = out_row; out_row += R; have = true;
     };
-    auto run_group = [&](int64_t n, int64_t warm_from, auto warm_tag) {
+    auto run_group = [&](int64_t n, int snap_at, auto snap_tag) {
         bool settled = true;
         if (ENV) {
             const double q_last = (double)(n + R - 1) / a.rate;
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) settled &= q_last < seg[i].end;
+            for (int i = 0; i < VPT; ++i) settled &= q_last < seg_end[i];
             settled = __all(settled);
         }
-        if (ENV && !settled) group(n, warm_from, warm_tag, std::true_type{});
-        else group(n, warm_from, warm_tag, std::false_type{});
+        if (ENV && !settled) group(n, snap_at, snap_tag, std::true_type{});
+        else group(n, snap_at, snap_tag, std::false_type{});
     };
 
+    const int snap_group = (a.N - a.ctx) / R, snap_at = (a.N - a.ctx) % R;     // (N > ctx: host-checked)
     for (int bi = 0; bi < nb; ++bi) {
         const int64_t p_b = p_first + (int64_t)bi * a.N;
         const bool more = bi + 1 < nb;
-        const int64_t warm_from = p_b + a.N - a.ctx;                           // (N > ctx: host-checked)
-        const int64_t warm_groups_from = more ? p_b + ((a.N - a.ctx) / R) * R : p_b + a.N;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < VPT; ++i) wa0[i] = wa1[i] = wb0[i] = wb1[i] = 0.0;
-        }
+        const int64_t n_snap = more ? p_b + (int64_t)snap_group * R : p_b + a.N;
         int64_t n = p_b;
-        for (; n < warm_groups_from; n += R) run_group(n, warm_from, std::false_type{});
-        for (; n < p_b + a.N; n += R) run_group(n, warm_from, std::true_type{});
+        for (; n < n_snap; n += R) run_group(n, 0, std::false_type{});
         if (more) {
+            run_group(n, snap_at, std::true_type{});
+            n += R;
+        }
+        for (; n < p_b + a.N; n += R) run_group(n, 0, std::false_type{});
+        if (more) {                                                            // the next block's chains: cold-started ctx rows ago
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) { za0[i] = wa0[i]; za1[i] = wa1[i]; zb0[i] = wb0[i]; zb1[i] = wb1[i]; }
+            for (int i = 0; i < VPT; ++i) {
+                restart(a1a[i], a2a[i], a.ctx, sa0[i], sa1[i], za0[i], za1[i]);
+                restart(a1b[i], a2b[i], a.ctx, sb0[i], sb1[i], zb0[i], zb1[i]);
+            }
         }
     }
     if (have) folded.finish(pend, pend_row, R);

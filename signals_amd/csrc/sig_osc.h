@@ -102,6 +102,21 @@ __device__ __forceinline__ float osc_sine_f32_fast(double f0, double d, double j
     return __uint_as_float(__float_as_uint(__builtin_amdgcn_sinf(rev)) ^ flip);
 }
 
+// Sawtooth for the fused kernels, whose oscillator sample feeds an f64 filter: m = t' - floor(t') as ONE instruction
+// (v_fract_f64).  It differs from sig_npmod_pow2 only where the rounded subtraction would reach 1.0 (t' in (-2^-54, 0)):
+// v_fract_f64 answers the largest double below 1 instead, 2.2e-16 away in the sample; the per-node oscillator kernel, whose
+// float32 output is compared bit for bit, keeps the two-instruction form.
+__device__ __forceinline__ double osc_sawtooth_fract(double t) {
+    return fma(__builtin_amdgcn_fract(t - 0.5), 2.0, -1.0);
+}
+
+template <int KIND> __device__ __forceinline__ double osc_wave_fused(double t) {
+    if (KIND == SIG_OSC_SQUARE) return osc_square(t);
+    if (KIND == SIG_OSC_SAWTOOTH) return osc_sawtooth_fract(t);
+    if (KIND == SIG_OSC_TRIANGLE) return osc_triangle(t);
+    return osc_sine(t);
+}
+
 template <int KIND, typename OUT> __device__ __forceinline__ OUT osc_wave(double t) {
     if (KIND == SIG_OSC_SINE) {
         if (sizeof(OUT) == 4) return (OUT)osc_sine_f32(t);
