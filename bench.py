@@ -241,7 +241,7 @@ def cpu_baseline_sharded(p, voices, frames, workers, blocks=128):
 
 
 # --------------------------------------------------------------------------------------------------- other configs
-def run_config(name: str, steps: int = 12) -> dict:
+def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
     """BASELINE.json's C3 / C5 on this GPU through the engine's default schedule: throughput, per-kernel table, the
     dominant kernel's roofline, and max-abs error of the first rendered batch (the timed launch geometry) against the
     CPU oracle on whole-width blocks."""
@@ -252,10 +252,12 @@ def run_config(name: str, steps: int = 12) -> dict:
     if name == 'C3':
         V, channels, N, K = 1024, 1, 1024, 1024              # 1.07 G voice-samples per batch, like the headline's
         p = cfg.c3_params(V)
+        steps = steps or 30
         node, workload = cfg.c3_graph(p), f'C3: {V}-voice Sawtooth->LowPass->LowPass->(x ADSR)->SumBus(mono), 48 kHz, {N}-frame blocks, {K} blocks per batch'
     else:
         V, channels, N, K = 4096, 4096, 256, 64
         p = cfg.c5_params(V)
+        steps = steps or 100
         node, workload = cfg.c5_graph(p), f'C5: {V}-voice Sine->LowPass->MixMatrix(64x64), 48 kHz, {N}-frame blocks, {K} blocks per batch'
     timer = KernelTimer()
     r = BatchRenderer(node, channels, RATE, timer=timer)
@@ -275,15 +277,18 @@ def run_config(name: str, steps: int = 12) -> dict:
             errs[str(b)] = float(np.max(np.abs(first[b * N:(b + 1) * N].double().cpu().numpy() - ref)))
         sample = f'all {V} mixed voices, blocks 0 and {K - 1} of the first {K}-block batch vs the CPU oracle'
     del first
-    pos = N * K
-    for _ in range(2):
-        r.render(pos, N, K); pos += N * K
-    torch.cuda.synchronize(); timer.reset()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        r.render(pos, N, K); pos += N * K
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed(K, steps, pos):
+        t_end = time.perf_counter() + prewarm_s                                # the oracle above left the GPU idle: clocks back up first
+        while time.perf_counter() < t_end:
+            r.render(pos, N, K); pos += N * K
+            torch.cuda.synchronize()
+        timer.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render(pos, N, K); pos += N * K
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, pos
+    dt, pos = timed(K, steps, N * K)
     summ = timer.summary()
     from signals_amd import _native
 
@@ -311,7 +316,15 @@ def run_config(name: str, steps: int = 12) -> dict:
                     'instruction': 'v_mfma_f32_32x32x2_f32 (exact f32; 155 TFLOP/s measured back to back)',
                     'hbm': {k: roof[k] for k in ('achieved', 'peak', 'unit', 'frac', 'algo_bytes_per_voice_sample')}}
     full_scale = float(np.max(np.abs(ref)))
-    return {'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
+    extra = {}
+    if name == 'C3':
+        # the same stream in batches as long as the headline's: one history block per 16 blocks instead of per 4
+        K4 = 4096
+        dt4, pos = timed(K4, 10, pos)
+        extra['long_batches'] = {'blocks_per_batch': K4, 'value': V * N * K4 * 10 / dt4 / 1e6, 'unit': 'Msamples/s',
+                                 'ms_per_step': dt4 / 10 * 1e3, 'steps': 10,
+                                 'launch_geometry': dict(zip(('voices_per_lane', 'blocks_per_lane'), _native.fused_cascade_geometry(V, K4)))}
+    return {**extra, 'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
             'steps': steps, 'roofline': roof, 'kernels': kernels,
             'max_abs_error': {'per_block': errs, 'max': max(errs.values()), 'full_scale': full_scale,
                               'max_relative_to_full_scale': max(errs.values()) / max(1.0, full_scale),

@@ -667,17 +667,19 @@ def set_fused_cascade_tuning(voices_per_lane: int = 0, blocks_per_lane: int = 0)
 
 
 def fused_cascade_model(voices: int, block_frames: int, nblocks: int, context: int = 100, bus_channels: int = 1,
-                        osc_ops: float = 6.0, envelope: bool = True) -> dict:
+                        osc_ops: float = 5.0, envelope: bool = True) -> dict:
     """f64-rate VALU instructions per stored voice-sample of `fused_cascade_bus` (bench.py's roofline): the exact-phase
-    oscillator (6 for a Sawtooth: t = q * hertz + phase, t - 0.5, floor, subtract, 2 m - 1) and the inner filter (4) on
-    every row a lane walks -- span * N output rows, one history block of N + context rows per span, context warm-up rows
-    per further block -- the outer filter (4) on N + context rows per block, envelope (3), C bus FMAs and the folded flush"""
+    oscillator (5 for a Sawtooth: t = q * hertz + phase, t - 0.5, v_fract_f64, 2 m - 1) and the inner filter (4) on every
+    row a lane walks -- span * N output rows and one history block of N + context rows per span -- the outer filter (4)
+    on the output rows and the history's last `context` rows, envelope x weight (C) and bus (C) FMAs, the folded flush,
+    and the two restarts per (voice, block boundary) (2x2 power by squaring: 10 products of 8 + 6 for `context` = 100)"""
     vpt, span = fused_cascade_geometry(voices, nblocks)
     n, c = block_frames, context
     walked = (span * n + n + c) / (span * n)                    # oscillator + inner filter rows per output row
-    warm = (span - 1) * c / (span * n)                          # next-block warm-up chains (inner + outer) beside output rows
-    ops = osc_ops * walked + 4.0 * (walked + warm) + 4.0 * (1.0 + c / n) + (3.0 if envelope else 0.0) + bus_channels \
-        + 17.0 * bus_channels / (16 * vpt)
+    products = max(c, 1).bit_length() - 1 + bin(max(c, 1)).count('1')
+    restart = 8.0 * products + 6.0
+    ops = (osc_ops + 4.0) * walked + 4.0 * (1.0 + c / (span * n)) + (bus_channels if envelope else 0.0) + bus_channels \
+        + 17.0 * bus_channels / (16 * vpt) + restart * (2 * (span - 1) + 1) / (span * n)
     return {'f64_ops_per_voice_sample': ops, 'voices_per_lane': vpt, 'blocks_per_lane': span,
             'rows_walked_per_output_row': walked}
 

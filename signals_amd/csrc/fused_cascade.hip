@@ -257,17 +257,30 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     if (have) folded.finish(pend, pend_row, R);
 }
 
-// Launch geometry: voices per lane and blocks per lane.  Every span walks one extra block (the history), so long spans
-// waste less -- but the launch should still put a wave on every SIMD (1024): the span grows only while it does.
+// Launch geometry: voices per lane and blocks per lane.  Two costs pull apart: every span walks one extra block of
+// oscillator + inner filter (the history: ~10.6 instructions per row against ~17 per output row), and every output row
+// costs ~6 instructions per LANE whatever the lane carries (cross-lane fold, n / rate broadcast, loop) -- so per
+// voice-sample  6 / vpt + 12 / span  on top of the arithmetic.  The cheapest pair that still puts a wave on every SIMD
+// (1024) wins, ties to more voices per lane; when no pair fills the chip, the one with the most waves (ties to fewer voices per lane).  Measured at
+// V = 1024, N = 1024 (tools/time_cascade.py): K = 256 (2,2) 287 us against (4,1) 304-317; K = 1024 (4,4) 792 us,
+// (2,8) 840, (1,16) 1120; K = 4096 (4,16) 2760 us, (2,16) 2820, (4,8) 2880.
 int g_force_vpt = 0, g_force_span = 0;         // tuning / test hook (sig_fused_cascade_set_tuning); 0 = the heuristic below
 
 void cascade_geometry(int voices, int nblocks, int& vpt, int& span) {
     auto waves = [&](int v, int s) { return (int64_t)((voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((nblocks + s - 1) / s); };
-    vpt = 4;
-    while (vpt > 1 && waves(vpt, 1) < 1024) vpt >>= 1;
+    double best_cost = 0.0;
+    int64_t best_waves = -1;
+    vpt = 1; span = 1;
+    for (int v = 4; v >= 1; v >>= 1)
+        for (int s = 64; s >= 1; s >>= 1) {
+            if (s > 1 && s / 2 >= nblocks) continue;                           // (a span longer than the stream is the same launch)
+            const int64_t w = waves(v, s);
+            const double cost = 6.0 / v + 12.0 / s;
+            const bool fills = w >= 1024, best_fills = best_waves >= 1024;
+            const bool better = best_waves < 0 || (fills != best_fills ? fills : (fills ? cost < best_cost : w >= best_waves));
+            if (better) { vpt = v; span = s; best_cost = cost; best_waves = w; }
+        }
     if (g_force_vpt == 1 || g_force_vpt == 2 || g_force_vpt == 4) vpt = g_force_vpt;
-    span = 16;
-    while (span > 1 && waves(vpt, span) < 1024) span >>= 1;
     if (g_force_span >= 1) span = g_force_span;
 }
 

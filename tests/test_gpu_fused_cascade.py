@@ -166,7 +166,8 @@ def test_every_launch_geometry():
                     assert maxerr(got, f32(ref)) < 1.5e-6 * max(1.0, np.abs(ref).max()), (V, N, K, vpt, span)
     finally:
         _native.set_fused_cascade_tuning()
-    assert _native.fused_cascade_geometry(1024, 1024) == (4, 4) and _native.fused_cascade_geometry(1024, 256) == (4, 1)
+    assert _native.fused_cascade_geometry(1024, 1024) == (4, 4) and _native.fused_cascade_geometry(1024, 256) == (2, 2)
+    assert _native.fused_cascade_geometry(1024, 4096) == (4, 16) and _native.fused_cascade_geometry(1024, 64) == (1, 1)
     assert _native.fused_cascade_geometry(5, 3) == (1, 1)
 
 
