@@ -12,7 +12,7 @@ for f in *.hip; do
   o="${f%.hip}.o"
   stale=0
   [ -f "$o" ] || stale=1
-  for dep in "$f" sig_common.h sig_osc.h sig_biquad.h sig_adsr.h sig_bus_tile.h ../../include/signals_amd.h; do
+  for dep in "$f" sig_common.h sig_osc.h sig_biquad.h sig_adsr.h sig_bus_tile.h sig_mix_tile.h sig_steady.h ../../include/signals_amd.h; do
     [ "$stale" = 1 ] || { [ "$dep" -nt "$o" ] && stale=1; } || true
   done
   if [ "$stale" = 1 ]; then

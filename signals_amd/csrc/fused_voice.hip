@@ -32,12 +32,13 @@
 
 #include "sig_biquad.h"
 #include "sig_bus_tile.h"
+#include "sig_mix_tile.h"
 #include "sig_osc.h"
+#include "sig_steady.h"
 
 namespace {
 
-using sig_biquad::Biquad;
-using sig_biquad::design_butter2;
+using namespace sig_fused;
 
 template <int VPT> struct OutVec;
 template <> struct OutVec<1> { using type = float; };
@@ -65,55 +66,19 @@ template <> struct Occ<1> { static constexpr int lo = SIG_FUSED_OCC1 ? SIG_FUSED
 template <> struct Occ<2> { static constexpr int lo = SIG_FUSED_OCC2 ? SIG_FUSED_OCC2 : 1, hi = SIG_FUSED_OCC2 ? SIG_FUSED_OCC2 : 8; };
 template <> struct Occ<4> { static constexpr int lo = SIG_FUSED_OCC4 ? SIG_FUSED_OCC4 : 1, hi = SIG_FUSED_OCC4 ? SIG_FUSED_OCC4 : 8; };
 
-struct FusedArgs {
-    int type; double rate; int64_t position; int N, K, ctx, voices;
-    const double* hertz; int hs; const double* phase; int ps;
-    const double* cutoff; int cs; const double* gain; int gs;
-    float* out; int64_t out_ld; int voice_tiles; int* status;
-    const int64_t* pos_dev = nullptr;        // when set, the position is read from device memory (hipGraph replay)
-    const float* mix = nullptr;              // C == -1: the (64, 64) row-major mix matrix
-    int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
-    int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
-    const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
-    double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
-    int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
-    int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
-    int cutoff_rows = 1, gain_rows = 1;      // > 1: one (1,V)|(1,1) parameter row PER BLOCK (sig_fused_*_rows), row b at + b * (stride ? voices : 1)
-    // sig_fused_*_pair: the filter reads Mix(A, B, mix) (pair_op 1) or RingMod(A, B) (pair_op 2) of TWO oscillators
-    int pair_op = 0, kind2 = 0;
-    const double* hertz2 = nullptr; int hs2 = 0; const double* phase2 = nullptr; int ps2 = 0; const double* mixrow = nullptr; int ms = 0;
-};
-
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
 using sig_bus::kPairs;
 using sig_bus::kTileStride;
-constexpr int kMixTileRows = 32, kMixLdsStride = 68;   // MixMatrix sink: rows per MFMA tile, floats per LDS row (64 + 4 pad)
 
 struct BusArgs { const double* pan; int64_t pan_ld; double* partials; int64_t rows; };
-
-// sin(2 pi f) and cos(2 pi f) in f64 (~1 ulp), any |f| < 2^50: quarter-range reduction by the magic-number
-// rint of sig_osc.h, true 2 pi as hi + lo
-__device__ __forceinline__ double sin2pi(double f) {
-    const double u = fma(f, 2.0, sig_osc::kRoundMagic);
-    const double k = u - sig_osc::kRoundMagic;
-    const double rq = fma(k, -0.5, f);
-    const double y = sig_osc::sin_poly(fma(rq, sig_osc::kTwoPiHi, rq * sig_osc::kTwoPiLo));
-    return __hiloint2double(__double2hiint(y) ^ (int)(((unsigned)__double2loint(u) & 1u) << 31), __double2loint(y));
-}
-
-struct M2 { double a, b, c, d; };                                             // [[a, b], [c, d]]
-__device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
-    return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
-}
 
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb);   // below
 
 // C == 0: store (float)(weight * y) to a.out; C > 0: C bus channels into bus.partials; C == -1 (one voice per lane,
 // voices a multiple of 64): the MixMatrix sink -- the wave's 64 voices are one matrix group, every 32 rows of
 // float32 samples are staged in a wave-private LDS tile and multiplied by the 64 x 64 matrix on the matrix cores
-// exactly as mix_matrix.hip does (same fragment layout, same k order, same exact-f32 MFMA), then stored.  The
-// per-voice rows never touch HBM, and the walker's f64 VALU work of one wave overlaps the MFMAs of the other
-// wave on the SIMD.
+// (sig_mix_tile.h: each float32 as three bfloat16, six bf16 MFMAs per k-block), then stored.  The per-voice rows
+// never touch HBM.
 // ROWS: cutoff and gain are read per block (the reference reads a control port once per block, at the block's position:
 // chain/__init__.py:305-306 -- an LFO on a cutoff, a tremolo); the filter is then designed per block, the next block's
 // warm-up chain with the next block's design.  GAIN is ignored (a null gain pointer means 1).
@@ -126,7 +91,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     constexpr int R = kPairs / CC;         // rows per flush
     static_assert(!MIX || VPT == 1, "the MixMatrix sink maps one matrix group to one wave");
     using Vec = typename OutVec<VPT>::type;
-    __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? kMixTileRows * kMixLdsStride / 2 : 1)];
+    __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? sig_mix::kTileRows * sig_mix::kLdsStride / 2 : 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: block / tile indices in SGPRs
     double* tile = lds[(BUS || MIX) ? wave : 0];
@@ -209,49 +174,9 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     sig_bus::PipelinedTile<CC> stage(tile, lane, dstp, b_first * a.N);
     int64_t n_cur = p0 - c0;                                                   // absolute frame of the next row
 
-    // MixMatrix sink (mix_matrix.hip): B operands M[32h + ks][32 jt + i] in 64 VGPRs, rows staged as float32
-    using f32x16 = __attribute__((ext_vector_type(16))) float;
-    float* ftile = reinterpret_cast<float*>(tile);
-    float bm[MIX ? 2 : 1][MIX ? 32 : 1];
-    int mstaged = 0;
-    int64_t mrow0 = b_first * a.N;                                             // output row of tile row 0
-    if constexpr (MIX) {
-        const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            bm[0][ks] = a.mix[(32 * h + ks) * 64 + i];
-            bm[1][ks] = a.mix[(32 * h + ks) * 64 + 32 + i];
-        }
-    }
-    auto mix_flush = [&](int nrows) {
-        if constexpr (MIX) {
-            const int i = lane & 31, h = lane >> 5;
-            float af[32];                                                      // half-row x[i][32h .. 32h+31]: k(ks, h) = 32h + ks
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 t = *reinterpret_cast<const float4*>(ftile + i * kMixLdsStride + 32 * h + 4 * c);
-                af[4 * c] = t.x; af[4 * c + 1] = t.y; af[4 * c + 2] = t.z; af[4 * c + 3] = t.w;
-            }
-            f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-            for (int ks = 0; ks < 32; ++ks) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[0][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[1][ks], acc1, 0, 0, 0);
-            }
-            // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-            float* d = a.out + mrow0 * a.out_ld + (int64_t)vt * 64 + i;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (r < nrows) {
-                    d[(int64_t)r * a.out_ld] = acc0[reg];
-                    d[(int64_t)r * a.out_ld + 32] = acc1[reg];
-                }
-            }
-            mrow0 += nrows;
-            mstaged = 0;
-        }
-    };
+    // MixMatrix sink: rows staged as float32, 32 at a time through the matrix cores (sig_mix_tile.h)
+    std::conditional_t<MIX, sig_mix::Sink, int> sink{};
+    if constexpr (MIX) sink.init(a.mix, reinterpret_cast<float*>(tile), a.out + (int64_t)vt * 64, a.out_ld, b_first * a.N, lane);
 
     // one row of the lane's recurrences: y = output of the current block's chain; WARM rows also advance the
     // next block's warm-up chain on the same input
@@ -281,8 +206,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     sig_bus::FoldedGroup<CC> folded(tile, lane, dstp);                         // whole groups of R rows: sums folded in registers
     auto to_out = [&](const double (&y)[VPT], int64_t out_row) {
         if constexpr (MIX) {                                                   // rows arrive in order: stage, multiply every 32
-            ftile[mstaged * kMixLdsStride + lane] = (float)(y[0] * wt[0][0]);
-            if (++mstaged == kMixTileRows) mix_flush(kMixTileRows);
+            sink.stage((float)(y[0] * wt[0][0]));
             return;
         }
         float y32[VPT];
@@ -448,7 +372,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         }
     }
     if (BUS && stage.staged) stage.now();
-    if (MIX && mstaged) mix_flush(mstaged);
+    if constexpr (MIX) sink.finish();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -475,18 +399,6 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // rows of `voices` doubles): the filter, the oscillator step, H(e^{j theta}), T_c for c = ctx and for the launch's first
 // block (c = min(ctx, position)), and the decay bound.
 enum { SC_NA1, SC_NA2, SC_SCALE, SC_K2C, SC_ST, SC_CT, SC_HRE, SC_HIM, SC_ND, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
-constexpr double kHomogeneousTol = 1e-11;     // of one voice's full scale (unit-amplitude oscillator, before gain and pan)
-
-// per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^26 cycles over
-// the span (as for the walker's Sine recurrence), at most a quarter turn per row, and sin(theta) not tiny (the map
-// from (yss, dss) back to the complex amplitude divides by it: below ~8 Hz at 48 kHz the walker is used instead)
-__device__ __forceinline__ bool steady_voice_ok(double hz, double ph, double rate, double st, double q_first, double q_last) {
-    const double t_first = q_first * hz + ph, t_last = q_last * hz + ph;
-    const double d = hz / rate;
-    const double dr = d - rint(d);
-    return fabs(t_first) < sig_osc::kSineFastMaxT && fabs(t_last) < sig_osc::kSineFastMaxT && fabs(dr) <= 0.25 &&
-           fabs(st) >= 1e-3;
-}
 
 // does the steady kernel take the wave of voices [v0, v0 + vpt) x 64 lanes for the span starting at frame p0?
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb) {
@@ -501,65 +413,6 @@ __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt,
 }
 
 // the closed form's per-voice constants (see the enum above), derived from the voice's parameters
-struct SteadyVoice { bool ok; double na1, na2, scale, k2c, st, ct, hre, him, nd; M2 T, T0; };
-
-template <bool GAIN>
-__device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int v)
-{
-    using sig_biquad::Cx; using sig_biquad::cx_mul; using sig_biquad::cx_div;
-    SteadyVoice r;
-    Biquad q;
-    r.ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
-    const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
-    const double a1 = q.a1, a2 = q.a2;
-    const double d = a.hertz[(int64_t)v * a.hs] / a.rate;
-    const double dr = d - rint(d);
-    const double st = sin2pi(dr), ct = sin2pi(dr + 0.25), sh = sin2pi(0.5 * dr);
-    const Cx z = {ct, -st};                                                    // e^{-j theta}
-    const Cx z2 = cx_mul(z, z);
-    const Cx H = cx_div({1.0 + s2 * z.re + z2.re, s2 * z.im + z2.im}, {1.0 + a1 * z.re + a2 * z2.re, a1 * z.im + a2 * z2.im});
-    const Cx P = {H.re - 1.0, H.im};                                           // z0ss_{n-1} = Im(P u_n)
-    const Cx Pe = cx_mul(P, {ct, st});
-    const Cx Q = {Pe.re - s2 + a1 * H.re, Pe.im + a1 * H.im};                  // z1ss_{n-1} = Im(Q u_n)
-    const double alpha = 2.0 * sh * sh / st, beta = 1.0 / st;                  // wr = alpha yss + beta dss, wi = yss
-    auto make_T = [&](int c) {                                                 // T_c = -A^c Mss(c)
-        const double cf = (double)c * dr;                                      // c theta in revolutions
-        const Cx E = cx_div({sin2pi(cf + 0.25), -sin2pi(cf)}, H);              // e^{-j c theta} / H
-        const Cx PE = cx_mul(P, E), QE = cx_mul(Q, E);
-        const M2 Mss = {fma(PE.im, alpha, PE.re), PE.im * beta, fma(QE.im, alpha, QE.re), QE.im * beta};
-        M2 Ac = {1.0, 0.0, 0.0, 1.0}, Ap = {-a1, 1.0, -a2, 0.0};               // A^c by squaring
-        for (int e = c; e > 0; e >>= 1) {
-            if (e & 1) Ac = m2_mul(Ac, Ap);
-            Ap = m2_mul(Ap, Ap);
-        }
-        const M2 t = m2_mul(Ac, Mss);
-        return M2{-t.a, -t.b, -t.c, -t.d};
-    };
-    r.T = make_T(a.ctx);
-    const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
-    r.T0 = (c0 == a.ctx) ? r.T : make_T(c0);
-    // Rows after a cold start until the homogeneous part is below kHomogeneousTol of the voice's full scale, for good:
-    // in the coordinates S x in which A is a rotation times the pole radius rho = sqrt(a2) the state shrinks by exactly
-    // rho per row, so |yh_n| <= cond(S) rho^n |x_0| with x_0 = minus the steady-state DF2T state, |x_0| <= sqrt(|P|^2 + |Q|^2)
-    // (b0-normalised, hence the factor b0).  S^-1 = [[1, 0], [a1/2, d]], d = sqrt(a2 - a1^2/4) (eigenvector (1, a1 + lambda));
-    // its condition number from the Frobenius norm and the determinant.  NaN or real poles: never (infinity).
-    r.nd = __builtin_inf();
-    {
-        const double d2 = a2 - 0.25 * a1 * a1;
-        if (r.ok && d2 > 0.0 && a2 > 0.0 && a2 < 1.0) {
-            const double dd = sqrt(d2), f2 = 1.0 + 0.25 * a1 * a1 + d2;
-            const double kappa = (f2 + sqrt(fmax(f2 * f2 - 4.0 * d2, 0.0))) / (2.0 * dd);
-            const double amp = q.b0 * kappa * sqrt(P.re * P.re + P.im * P.im + Q.re * Q.re + Q.im * Q.im);
-            const double rows = (amp > kHomogeneousTol) ? log(kHomogeneousTol / amp) / (0.5 * log(a2)) : 0.0;
-            if (rows == rows) r.nd = ceil(rows) + 1.0;
-        }
-    }
-    r.na1 = -a1; r.na2 = -a2;
-    r.scale = GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0;
-    r.k2c = 2.0 * ct; r.st = st; r.ct = ct; r.hre = H.re; r.him = H.im;
-    return r;
-}
-
 template <bool GAIN>
 __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* __restrict__ consts)
 {
@@ -629,16 +482,6 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
 }
 
 // wave-wide maximum of a non-negative int, the same value in every lane
-__device__ __forceinline__ int wave_max_int(int x) {
-#pragma unroll
-    for (int d = 1; d < SIG_WAVE; d <<= 1) {
-        const int y = __shfl_xor(x, d, SIG_WAVE);
-        x = (y > x) ? y : x;
-    }
-    return __builtin_amdgcn_readfirstlane(x);
-}
-
-constexpr int kNeverDrops = 0x3fffffff;
 
 // the row-group variants of fused_steady_bus_kernel: "the first M of the lane's VPT voice slots still carry their
 // homogeneous part", largest first
@@ -892,144 +735,6 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     }
     if (have) folded.finish(pend, pend_row, R);
     if (stage.staged) stage.now();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The closed form feeding the MixMatrix sink (BASELINE config 5, Sine): one voice per lane, a wave = one 64-voice
-// matrix group over `span` blocks.  Per stored sample 1 (steady two-term recurrence) + 1 (scale) + a conversion, plus 3
-// while the wave's slowest voice still carries its homogeneous part, instead of the walker's 10.45 -- so the launch
-// costs little more than its 64 MFMAs per 32 rows (f64 vector work and the matrix pipe do not overlap on a SIMD).  The
-// per-voice constants are derived by each wave for its own 64 voices (no workspace in this entry point).  Waves with a
-// voice outside the closed form's range walk their blocks row by row with the exact phase.
-template <bool GAIN>
-__global__ __launch_bounds__(256) void fused_steady_mix_kernel(FusedArgs a)
-{
-    using f32x16 = __attribute__((ext_vector_type(16))) float;
-    __shared__ __attribute__((aligned(16))) float lds[4][kMixTileRows * kMixLdsStride];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* ftile = lds[wave];
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    const int vt = (int)(item % a.voice_tiles);
-    const int64_t b_first = (item / a.voice_tiles) * a.span;
-    if (b_first >= a.K) return;                                               // wave-uniform
-    const int nb = (int)((a.K - b_first < (int64_t)a.span) ? a.K - b_first : (int64_t)a.span);
-    const int v = vt * SIG_WAVE + lane;                                       // voices % 64 == 0 (host-checked): every lane is live
-    const int64_t p0 = a.position + b_first * a.N;
-
-    const SteadyVoice sv = steady_constants<GAIN>(a, v);
-    if (!sv.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
-    const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
-
-    // MixMatrix sink (mix_matrix.hip): B operands M[32h + ks][32 jt + i] in 64 VGPRs, rows staged as float32
-    float bm[2][32];
-    {
-        const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            bm[0][ks] = a.mix[(32 * h + ks) * 64 + i];
-            bm[1][ks] = a.mix[(32 * h + ks) * 64 + 32 + i];
-        }
-    }
-    int mstaged = 0;
-    int64_t mrow0 = b_first * a.N;                                             // output row of tile row 0
-    auto mix_flush = [&](int nrows) {
-        const int i = lane & 31, h = lane >> 5;
-        float af[32];                                                          // half-row x[i][32h .. 32h+31]: k(ks, h) = 32h + ks
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 t = *reinterpret_cast<const float4*>(ftile + i * kMixLdsStride + 32 * h + 4 * c);
-            af[4 * c] = t.x; af[4 * c + 1] = t.y; af[4 * c + 2] = t.z; af[4 * c + 3] = t.w;
-        }
-        f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[0][ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bm[1][ks], acc1, 0, 0, 0);
-        }
-        // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        float* d = a.out + mrow0 * a.out_ld + (int64_t)vt * 64 + i;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            if (r < nrows) {
-                d[(int64_t)r * a.out_ld] = acc0[reg];
-                d[(int64_t)r * a.out_ld + 32] = acc1[reg];
-            }
-        }
-        mrow0 += nrows;
-        mstaged = 0;
-    };
-    auto stage = [&](double y) {                                               // rows arrive in order: stage, multiply every 32
-        ftile[mstaged * kMixLdsStride + lane] = (float)(y * sv.scale);
-        if (++mstaged == kMixTileRows) mix_flush(kMixTileRows);
-    };
-
-    const double q_first = (double)p0 / a.rate, q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
-    if (!__all(steady_voice_ok(hz, ph, a.rate, sv.st, q_first, q_last) && (a.N >= a.ctx || p0 >= a.ctx))) {
-        // the plain way: every block on its own from zero state over [c context rows | block], exact per-row phase
-        const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
-#pragma unroll 1
-        for (int bi = 0; bi < nb; ++bi) {
-            const int64_t p_b = p0 + (int64_t)bi * a.N;
-            const int c = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
-            double z0 = 0.0, z1 = 0.0;
-#pragma unroll 1
-            for (int r = -c; r < a.N; ++r) {
-                const double t = (double)(p_b + r) / a.rate * hz + ph;         // osc.py:32
-                const double x = (double)sig_osc::osc_sine_f32(t);
-                const double y = x + z0;
-                z0 = fma(sv.na1, y, fma(s2, x, z1));
-                z1 = fma(sv.na2, y, x);
-                if (r >= 0) stage(y);                                          // wave-uniform
-            }
-        }
-        if (mstaged) mix_flush(mstaged);
-        return;
-    }
-
-    // steady-state oscillator at rows p0 - 1 and p0: w = H e^{j phi}, yss_p0 = Im w, yss_{p0-1} = Im(w e^{-j theta})
-    double ya, yb;
-    {
-        const double t_first = q_first * hz + ph;                              // osc.py:32
-        const double f0 = t_first - rint(t_first);                             // exact, |f0| <= 0.5
-        const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
-        const double wr = fma(sv.hre, ur, -(sv.him * ui)), wi = fma(sv.hre, ui, sv.him * ur);
-        yb = wi;
-        ya = fma(wi, sv.ct, -(wr * sv.st));
-    }
-    const int nd_total = wave_max_int((sv.nd < (double)kNeverDrops) ? (int)sv.nd : kNeverDrops);   // NaN: never
-    for (int bi = 0; bi < nb; ++bi) {
-        const bool first = (b_first + bi == 0);
-        const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
-        int live_rows = (nd_total > c) ? nd_total - c : 0;                     // wave-uniform: rows that still carry the homogeneous part
-        live_rows = (live_rows < a.N) ? live_rows : a.N;
-        double z0h = 0.0, z1h = 0.0;
-        if (live_rows > 0) {
-            const M2& t = first ? sv.T0 : sv.T;
-            const double dss = fma(sv.k2c, yb, -ya) - yb;                      // yss_{p+1} - yss_p
-            z0h = fma(t.a, yb, t.b * dss);
-            z1h = fma(t.c, yb, t.d * dss);
-        }
-        int r = 0;
-#pragma unroll 2
-        for (; r < live_rows; ++r) {
-            const double y = yb + z0h, yh = z0h;
-            z0h = fma(sv.na1, yh, z1h);
-            z1h = sv.na2 * yh;
-            const double nx = fma(sv.k2c, yb, -ya);
-            ya = yb; yb = nx;
-            stage(y);
-        }
-#pragma unroll 4
-        for (; r < a.N; ++r) {
-            const double y = yb;
-            const double nx = fma(sv.k2c, yb, -ya);
-            ya = yb; yb = nx;
-            stage(y);
-        }
-    }
-    if (mstaged) mix_flush(mstaged);
 }
 
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
@@ -1332,16 +1037,10 @@ int launch_mix(FusedArgs a, hipStream_t stream)
     int vpt;
     pick_geometry(a, 1, vpt, a.span);                                          // one voice per lane: a wave = one matrix group
     if (KIND == SIG_OSC_SINE && (tuning().steady < 0 ? 1 : tuning().steady)) { // closed form per wave (or its built-in plain fallback)
-        // One block per wave unless told otherwise: the closed form has no warm-up rows to amortise over a span, and the
-        // launch is paced by its MFMAs (57 of ~115 us for config 5: 8.6 GFLOP at the 155 TFLOP/s the exact-f32 MFMA
-        // reaches) plus the f64 vector phase, which do not overlap on a SIMD -- more, shorter waves pack the SIMDs better
-        // (span 1 / 2 / 4 / 8: 117 / 133 / 129 / 243 us).
-        if (tuning().span == 0) a.span = 1;
+        // (fused_mix.hip; blocks per wave: see launch_steady_mix)
+        if (tuning().span == 0) a.span = 0;
         a.voice_tiles = a.voices / SIG_WAVE;
-        const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
-        if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-        fused_steady_mix_kernel<GAIN><<<(unsigned)nwg, 256, 0, stream>>>(a);
-        return sig_launch_status();
+        return launch_steady_mix(a, GAIN, stream);
     }
     return launch_walk<KIND, GAIN, -1>(a, BusArgs{nullptr, 0, nullptr, 0}, 1, stream);
 }
