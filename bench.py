@@ -307,14 +307,18 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
     else:
         roof = hbm_roofline(kernels, dom, pmc_traffic(f'{name}/{fam}'))
         if fam == 'fused_osc_biquad_mix':
-            # chain + matrix in one launch: paced by the exact-f32 MFMAs (128 flop per voice-sample) plus the f64 vector
-            # phase of the closed form, which do not overlap on a SIMD (tools/ubench/mfma_valu_overlap.hip); the stores
-            # (4 B per voice-sample) hide under them
-            tf = 128 * V * N * K / (kernels[dom]['avg_ms'] * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3,
-                    'traffic': roof['traffic'], 'flop_per_voice_sample': 128, 'avg_launch_ms': kernels[dom]['avg_ms'],
-                    'instruction': 'v_mfma_f32_32x32x2_f32 (exact f32; 155 TFLOP/s measured back to back)',
-                    'hbm': {k: roof[k] for k in ('achieved', 'peak', 'unit', 'frac', 'algo_bytes_per_voice_sample')}}
+            # chain + matrix in one launch.  The only HBM traffic is the mixed float32 rows (4 B per voice-sample), and that
+            # is the roof the launch is closest to since the contraction moved to bf16 MFMAs (sig_mix_tile.h: float32 =
+            # three bfloat16, six exact products per k-block -> 768 executed flop per voice-sample at the 2.5 PFLOP/s bf16
+            # rate instead of 128 at the 157 TFLOP/s of v_mfma_f32_32x32x2_f32).  Measured by leaving parts out
+            # (DESIGN.md 7): stores ~22 us, MFMAs ~28 us, vector work (rows, float32 -> 3 x bf16) ~21 us, per-wave set-up
+            # ~6 us of the launch, adding up rather than overlapping at two waves per SIMD.
+            secs = kernels[dom]['avg_ms'] * 1e-3
+            roof['mfma'] = {'executed_flop_per_voice_sample': 768, 'algorithmic_flop_per_voice_sample': 128,
+                            'achieved': 768 * V * N * K / secs / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s (bf16, dense)',
+                            'frac': 768 * V * N * K / secs / 1e12 / 2500.0,
+                            'instruction': 'v_mfma_f32_32x32x16_bf16, 48 per 32-row x 64-voice tile'}
+            roof['store_rate_of_a_plain_fill_GBs'] = 6900.0     # torch fill_ of 256 MiB on this GPU (tools/ubench/torch_bandwidth.py): the practical write roof
     full_scale = float(np.max(np.abs(ref)))
     extra = {}
     if name == 'C3':
@@ -329,7 +333,7 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
             'max_abs_error': {'per_block': errs, 'max': max(errs.values()), 'full_scale': full_scale,
                               'max_relative_to_full_scale': max(errs.values()) / max(1.0, full_scale),
                               'bar': '1e-6 of full scale: the outputs are sums over voices (full scale > 1), stored as float32 '
-                                     '(one ulp at full scale = %.1e); C5 contracts in exact-f32 MFMA as BASELINE config 5 defines it. '
+                                     '(one ulp at full scale = %.1e); C5 contracts exact products of the float32 rows and matrix in float32 accumulators. '
                                      'Both nodes are build-defined (SURVEY.md 8a A11): parity is against the oracle definition'
                                      % float(np.spacing(np.float32(full_scale))),
                               'sample': sample}}
