@@ -238,20 +238,24 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     for (int bi = 0; bi < nb; ++bi) {
         const int64_t p_b = p_first + (int64_t)bi * a.N;
         const bool more = bi + 1 < nb;
-        const int64_t n_snap = more ? p_b + (int64_t)snap_group * R : p_b + a.N;
+        const bool snap = more && a.ctx > 0;                                   // (no context rows: the next block starts from zero state)
+        const int64_t n_snap = snap ? p_b + (int64_t)snap_group * R : p_b + a.N;
         int64_t n = p_b;
         for (; n < n_snap; n += R) run_group(n, 0, std::false_type{});
-        if (more) {
+        if (snap) {
             run_group(n, snap_at, std::true_type{});
             n += R;
         }
         for (; n < p_b + a.N; n += R) run_group(n, 0, std::false_type{});
-        if (more) {                                                            // the next block's chains: cold-started ctx rows ago
+        if (snap) {                                                            // the next block's chains: cold-started ctx rows ago
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 restart(a1a[i], a2a[i], a.ctx, sa0[i], sa1[i], za0[i], za1[i]);
                 restart(a1b[i], a2b[i], a.ctx, sb0[i], sb1[i], zb0[i], zb1[i]);
             }
+        } else if (more) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) za0[i] = za1[i] = zb0[i] = zb1[i] = 0.0;
         }
     }
     if (have) folded.finish(pend, pend_row, R);

@@ -171,6 +171,44 @@ def test_every_launch_geometry():
     assert _native.fused_cascade_geometry(5, 3) == (1, 1)
 
 
+def test_other_context_lengths_through_the_c_abi(monkeypatch):
+    """the reference's context is 100 frames (fx.py:82-83); the entry point takes it as an argument, and the kernel's
+    restarts (running chain minus A^ctx times its state ctx rows ago) must hold for any: 1, 37, 255 of a 256-frame block
+    against the oracle with its constant patched; 0 (no context: every block from zero state) against the same voices
+    rendered one block per launch"""
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    V, N, K = 70, 256, 6
+    p = params(V, 9)
+    p['cut1'][0, :6] = np.linspace(30.0, 150.0, 6)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    hz, ph, c1, c2 = up(p['hertz']), up(p['phase']), up(p['cut1']), up(p['cut2'])
+    env = {k: up(v) for k, v in p['env'].items()}
+
+    def launch(ctx, pos, k, history):
+        out = torch.full((k * N, 1), float('nan'), device='cuda')
+        _native.fused_cascade_bus('Sawtooth', 'lp', 'lp', RATE, pos, history, N, k, ctx, V, hz, ph, c1, c2, None, env, None, out)
+        return out.cpu().numpy()
+
+    try:
+        for ctx in (1, 37, 255):
+            monkeypatch.setattr(R, 'CONTEXT_FRAMES', ctx)
+            node = R.Binary('RingMod', R.Filter('lp', R.Filter('lp', R.Osc('Sawtooth', R.Fixed(p['hertz']), R.Fixed(p['phase'])),
+                                                               R.Fixed(p['cut1']), ctx=ctx), R.Fixed(p['cut2']), ctx=ctx), R.Adsr(**p['env']))
+            ref = R.sum_bus(R.render_stream(node, 0, N, K, V), None)
+            for vpt, span in ((0, 0), (2, 3), (4, 1)):
+                _native.set_fused_cascade_tuning(vpt, span)
+                got = np.concatenate([launch(ctx, 0, 4, 0), launch(ctx, 4 * N, K - 4, 3 * N)])
+                assert maxerr(got, f32(ref)) < 1e-6 * np.abs(ref).max(), (ctx, vpt, span)
+        _native.set_fused_cascade_tuning(2, 4)
+        whole = launch(0, 0, K, 0)
+        _native.set_fused_cascade_tuning(1, 1)
+        single = np.concatenate([launch(0, b * N, 1, b * N) if b == 0 else launch(0, b * N, 1, (b - 1) * N) for b in range(K)])
+        assert np.isfinite(whole).all() and maxerr(whole, single) < 1e-6 * np.abs(single).max()
+    finally:
+        _native.set_fused_cascade_tuning()
+
+
 def test_bad_cutoff_in_either_filter_is_reported():
     from signals_amd import runtime
     V, N = 16, 256
