@@ -72,6 +72,14 @@ __device__ __forceinline__ void restart(double na1, double na2, int e, double s0
     z1 -= fma(m.c, s0, m.d * s1);
 }
 
+// The envelope stage a voice is in at time q, as a line in t.  Not inlined: it runs five times per voice over a whole stream,
+// and inlined into every row of the checked row groups it set the register budget of the whole kernel.
+struct StageLine { double end, slope, l; };
+__device__ __attribute__((noinline)) StageLine stage_line(const sig_env::AdsrRows& env, int v, double q) {
+    const sig_env::Segment s = sig_env::segment_at(sig_env::load_voice(env, v), q);
+    return {s.end, s.slope, fma(-s.slope, s.t0, s.l0)};
+}
+
 template <int KIND, int VPT, bool ENV, int C>
 __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_env::AdsrRows env)
 {
@@ -199,9 +207,9 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
                 y[i] = biquad(biquad(osc(q, i), s2a, a1a[i], a2a[i], za0[i], za1[i]), s2b, a1b[i], a2b[i], zb0[i], zb1[i]);
                 if (ENV && CHECKED && !(q < seg_end[i])) {                     // a stage boundary: per lane
                     const int v = (v0 + i < a.voices) ? v0 + i : vc;
-                    const sig_env::Segment s = sig_env::segment_at(sig_env::load_voice(env, v), q);
+                    const StageLine s = stage_line(env, v, q);
                     seg_end[i] = s.end;
-                    const double l = fma(-s.slope, s.t0, s.l0);                // level(t) = l + slope * t within the stage
+                    const double l = s.l;                                      // level(t) = l + slope * t within the stage
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch) { sw[ch][i] = s.slope * wt[ch][i]; lw[ch][i] = l * wt[ch][i]; }
                 }
