@@ -318,7 +318,8 @@ int sig_fused_cascade_bus(int osc_kind, int filt1_type, int filt2_type, int32_t 
 /* Introspection: voices per lane and consecutive blocks per lane sig_fused_cascade_bus uses (every span of blocks walks
  * one extra block of oscillator + inner filter, the history; bench.py's operation count depends on it). */
 int sig_fused_cascade_geometry(int32_t voices, int32_t nblocks, int32_t* voices_per_lane, int32_t* blocks_per_lane);
-/* Tuning / test hook (process-wide): force voices per lane (1, 2, 4; 0 = heuristic) and blocks per lane (>= 1; 0 = heuristic). */
+/* Tuning / test hook (process-wide): force voices per lane (1, 2, 4; 0 = heuristic) and blocks per lane (>= 1; 0 = heuristic;
+ * given as its negative: that many, and the voice tiles are added by a second launch instead of inside the kernel). */
 int sig_fused_cascade_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane);
 
 /* Latency mode of the same graph for a Sine oscillator: ONE block per launch, rows x voices parallelism (closed form
@@ -349,7 +350,8 @@ int sig_fused_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, in
 int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t voices, int32_t block_frames, int32_t nblocks,
                              int32_t context, int32_t* voices_per_lane, int32_t* blocks_per_lane, int32_t* closed_form);
 /* Tuning / test hook of the fused entry points: force the voices per lane (0 = heuristic), the blocks per lane
- * (0 = heuristic), the Sine closed form (-1 = heuristic, 0 = off, 1 = on) and the latency-mode prefix-scan kernel
+ * (0 = heuristic), the Sine closed form (-1 = heuristic, 0 = off, 1 = on, 2 = on with the voice tiles added by a second
+ * launch instead of inside the kernel) and the latency-mode prefix-scan kernel
  * (-1 = heuristic, 0 = off, 1 = on).  Process-wide, not thread-safe against concurrent launches; the initial values
  * come from SIG_FUSED_VPT / _SPAN / _STEADY / _SCAN, read once. */
 int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan);

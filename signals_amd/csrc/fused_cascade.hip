@@ -48,6 +48,7 @@ struct CascadeArgs {
     const double* cutoff1; int c1s; const double* cutoff2; int c2s; const double* gain; int gs;
     const double* pan; int64_t pan_ld; double* partials; int64_t rows;
     int voice_tiles, span; int* status;
+    float* out = nullptr; int64_t out_ld = 0;   // set: the kernel adds the voice tiles itself (sig_bus::sum_tiles_in_workgroup)
 };
 
 constexpr int kFoldTileDoubles = kPairs * sig_bus::kFoldStride;
@@ -81,12 +82,9 @@ __device__ __attribute__((noinline)) StageLine stage_line(const sig_env::AdsrRow
 }
 
 template <int KIND, int VPT, bool ENV, int C>
-__global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_env::AdsrRows env)
+__device__ __forceinline__ void cascade_wave(const CascadeArgs& a, const sig_env::AdsrRows& env, double* tile, int lane, int wave)
 {
     constexpr int R = kPairs / C;                                              // rows per group (the host checked N % R == 0)
-    __shared__ double lds[4][kFoldTileDoubles];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: keep what follows in SGPRs
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     }
 
     double* dstp = a.partials + (int64_t)vt * a.rows * C;                      // [tile][row][c]
-    sig_bus::FoldedGroup<C> folded(lds[wave], lane, dstp);
+    sig_bus::FoldedGroup<C> folded(tile, lane, dstp);
     double pend[4];
     int64_t pend_row = 0, out_row = b_first * a.N;
     bool have = false;
@@ -269,6 +267,16 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
     if (have) folded.finish(pend, pend_row, R);
 }
 
+template <int KIND, int VPT, bool ENV, int C>
+__global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_env::AdsrRows env)
+{
+    __shared__ double lds[4][kFoldTileDoubles];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: keep what follows in SGPRs
+    cascade_wave<KIND, VPT, ENV, C>(a, env, lds[wave], lane, wave);
+    if (a.out) sig_bus::sum_tiles_in_workgroup<C>(a.partials, a.voice_tiles, a.rows, a.span, a.K, a.N, a.out, a.out_ld, lane, wave);
+}
+
 // Launch geometry: voices per lane and blocks per lane.  Two costs pull apart: every span walks one extra block of
 // oscillator + inner filter (the history: ~10.6 instructions per row against ~17 per output row), and every output row
 // costs ~6 instructions per LANE whatever the lane carries (cross-lane fold, n / rate broadcast, loop) -- so per
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256) void fused_cascade_kernel(CascadeArgs a, sig_e
 // V = 1024, N = 1024 (tools/time_cascade.py): K = 256 (2,2) 287 us against (4,1) 304-317; K = 1024 (4,4) 792 us,
 // (2,8) 840, (1,16) 1120; K = 4096 (4,16) 2760 us, (2,16) 2820, (4,8) 2880.
 int g_force_vpt = 0, g_force_span = 0;         // tuning / test hook (sig_fused_cascade_set_tuning); 0 = the heuristic below
+int g_tile_sum_kernel = 0;                     // 1 (blocks_per_lane given as its negative): voice tiles added by partials_kernel
 
 void cascade_geometry(int voices, int nblocks, int& vpt, int& span) {
     auto waves = [&](int v, int s) { return (int64_t)((voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((nblocks + s - 1) / s); };
@@ -304,13 +313,14 @@ int launch(CascadeArgs a, const sig_env::AdsrRows& env, float* out, int64_t out_
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (sig_bus::tiles_sum_in_workgroup(a.voice_tiles) && !g_tile_sum_kernel) { a.out = out; a.out_ld = out_ld; }
     switch (vpt) {
         case 1: fused_cascade_kernel<KIND, 1, ENV, C><<<(unsigned)nwg, 256, 0, stream>>>(a, env); break;
         case 2: fused_cascade_kernel<KIND, 2, ENV, C><<<(unsigned)nwg, 256, 0, stream>>>(a, env); break;
         default: fused_cascade_kernel<KIND, 4, ENV, C><<<(unsigned)nwg, 256, 0, stream>>>(a, env); break;
     }
     const int err = sig_launch_status();
-    if (err) return err;
+    if (err || a.out) return err;                                              // (the kernel added the voice tiles itself)
     return sig_bus::launch_partials<C>(a.partials, a.voice_tiles, a.rows, out, out_ld, stream);
 }
 
@@ -351,9 +361,10 @@ extern "C" int sig_fused_cascade_geometry(int32_t voices, int32_t nblocks, int32
 
 extern "C" int sig_fused_cascade_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane)
 {
-    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0);
+    SIG_CHECK_ARG(voices_per_lane >= 0);
     g_force_vpt = voices_per_lane;
-    g_force_span = blocks_per_lane;
+    g_force_span = blocks_per_lane < 0 ? -blocks_per_lane : blocks_per_lane;   // negative: that span, and the voice tiles added by a second launch
+    g_tile_sum_kernel = blocks_per_lane < 0;
     return 0;
 }
 

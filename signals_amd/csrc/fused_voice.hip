@@ -70,7 +70,10 @@ template <> struct Occ<4> { static constexpr int lo = SIG_FUSED_OCC4 ? SIG_FUSED
 using sig_bus::kPairs;
 using sig_bus::kTileStride;
 
-struct BusArgs { const double* pan; int64_t pan_ld; double* partials; int64_t rows; };
+struct BusArgs {
+    const double* pan; int64_t pan_ld; double* partials; int64_t rows;
+    float* out = nullptr; int64_t out_ld = 0;   // set: the kernel adds the voice tiles itself (sig_bus::sum_tiles_in_workgroup), no partials_kernel launch
+};
 
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb);   // below
 
@@ -508,16 +511,11 @@ template <int VPT> struct SteadyVariants {
 template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ? SIG_STEADY_OCC16 : (VPT == 8) ? SIG_STEADY_OCC8 : 2; };
 
 template <int VPT, int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
-void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
+__device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
 {
     constexpr int R = kPairs / C;          // rows per flush
     constexpr int LC = SteadyVariants<VPT>::at(0);     // voice slots that can carry a homogeneous part (all of them up to 8 per lane)
     static_assert(R % 2 == 0, "the two-term recurrence rotates two registers per voice: row groups are even");
-    __shared__ double lds[4][kPairs * kTileStride];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
-    double* tile = lds[wave];                                                  // everything derived from it lives in SGPRs and branches are scalar
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
@@ -737,6 +735,17 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
     if (stage.staged) stage.now();
 }
 
+template <int VPT, int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
+void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
+{
+    __shared__ double lds[4][kPairs * kTileStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
+    steady_bus_wave<VPT, C>(a, bus, lds[wave], lane, wave);                    // everything derived from it lives in SGPRs and branches are scalar
+    if (bus.out) sig_bus::sum_tiles_in_workgroup<C>(bus.partials, a.voice_tiles, bus.rows, a.span, a.K, a.N, bus.out, bus.out_ld, lane, wave);
+}
+
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
 int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
     return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
@@ -744,13 +753,14 @@ int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
 
 // Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
 // _STEADY, _SCAN: read ONCE, when the first launch asks) and tests set them through sig_fused_set_tuning.
-struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1; };     // 0 / -1 = the launch heuristics decide
+struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1, tile_sum_kernel = 0; };     // 0 / -1 = the launch heuristics decide
 Tuning& tuning() {
     static Tuning t = [] {
         auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         Tuning u;
         u.vpt = env("SIG_FUSED_VPT", 0); u.span = env("SIG_FUSED_SPAN", 0);
         u.steady = env("SIG_FUSED_STEADY", -1); u.scan = env("SIG_FUSED_SCAN", -1);
+        if (u.steady == 2) { u.steady = 1; u.tile_sum_kernel = 1; }
         return u;
     }();
     return t;
@@ -872,6 +882,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
         a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
         const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
         if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        if (sig_bus::tiles_sum_in_workgroup(a.voice_tiles) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
         switch (vpt) {
             case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
             case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
@@ -880,7 +891,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
             default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
         }
         const int e2 = sig_launch_status();
-        if (e2) return e2;
+        if (e2 || bus.out) return e2;                                          // (the kernel added the voice tiles itself)
     } else {                                                                   // (Sine with the closed form: that launch did every wave)
         const int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
         if (err) return err;
@@ -1291,9 +1302,11 @@ extern "C" int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t 
 
 extern "C" int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan)
 {
-    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0 && closed_form >= -1 && scan >= -1);
+    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0 && closed_form >= -1 && closed_form <= 2 && scan >= -1);
     Tuning& t = tuning();
-    t.vpt = voices_per_lane; t.span = blocks_per_lane; t.steady = closed_form; t.scan = scan;
+    t.vpt = voices_per_lane; t.span = blocks_per_lane; t.scan = scan;
+    t.steady = (closed_form == 2) ? 1 : closed_form;                           // 2: closed form on, voice tiles added by partials_kernel
+    t.tile_sum_kernel = (closed_form == 2) ? 1 : 0;
     return 0;
 }
 

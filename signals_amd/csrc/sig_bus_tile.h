@@ -126,6 +126,53 @@ struct FoldedGroup {
     }
 };
 
+// The tile sum inside the producing kernel, for launches whose wave index is  item = 4 * workgroup + wave,  tile =
+// item % tiles,  span group = item / tiles  with tiles in {1, 2, 4}: the waves that hold one span group's tiles then sit in
+// ONE workgroup, so a workgroup barrier is all the hand-off needed (their partial stores, drained by vmcnt(0) before
+// the barrier, have left the CU through its write-through L1) -- no second launch, no ticket.  Wave t of the
+// group adds slice t of the group's rows, tiles in the same fixed order as partials_kernel: the same bits.  Every wave of
+// the workgroup calls this, also those without a span (ended waves do not count at a hardware barrier, so returning
+// early before it would be legal too; they simply find no rows).
+constexpr bool tiles_sum_in_workgroup(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4; }
+
+template <int C>
+__device__ __forceinline__ void sum_tiles_in_workgroup(const double* partials, int tiles, int64_t rows, int span, int K, int N,
+                                                       float* out, int64_t out_ld, int lane, int wave)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    const int t = (int)(item % tiles);
+    const int64_t b_first = (item / tiles) * span;
+    if (b_first >= K) return;
+    const int nb = (int)((K - b_first < (int64_t)span) ? K - b_first : (int64_t)span);
+    const int64_t n = (int64_t)nb * N * C, first = b_first * N * C, per = (n + tiles - 1) / tiles;
+    const int64_t lo = first + t * per, hi = (first + n < lo + per) ? first + n : lo + per;
+    // (plain loads: the producers are waves of this workgroup, whose stores went through this CU's write-through L1)
+    constexpr int U = 8;                                                       // loads in flight per lane and tile
+    int64_t i = lo + lane;
+    for (; i + (U - 1) * SIG_WAVE < hi; i += U * SIG_WAVE) {
+        double s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] = 0.0;
+        for (int k = 0; k < tiles; ++k) {                                      // fixed order
+            const double* src = partials + (int64_t)k * rows * C + i;
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] += src[u * SIG_WAVE];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = i + u * SIG_WAVE;
+            out[(j / C) * out_ld + (j % C)] = (float)s[u];
+        }
+    }
+    for (; i < hi; i += SIG_WAVE) {
+        double s = 0.0;
+        for (int k = 0; k < tiles; ++k) s += partials[(int64_t)k * rows * C + i];
+        out[(i / C) * out_ld + (i % C)] = (float)s;
+    }
+}
+
 template <int C>
 static __global__ __launch_bounds__(256) void partials_kernel(const double* __restrict__ partials, int tiles, int64_t rows,
                                                                float* __restrict__ out, int64_t out_ld)

@@ -171,6 +171,25 @@ def test_every_launch_geometry():
     assert _native.fused_cascade_geometry(5, 3) == (1, 1)
 
 
+def test_tile_sum_inside_the_kernel_equals_the_second_launch_bit_for_bit():
+    """1, 2 or 4 voice tiles: the cascade kernel adds them itself (sig_bus::sum_tiles_in_workgroup); a negative span through
+    the tuning hook keeps the second launch -- same additions in the same order, same bits, also when the batch is not a
+    multiple of the span and when the last workgroup has idle waves"""
+    from signals_amd import _native
+    try:
+        for V, vpt in ((40, 1), (200, 2), (200, 1), (520, 4), (700, 4)):      # 1, 2, 4, 3 (second launch either way), 3 tiles
+            p = params(V, 30 + V)
+            for N, K, span, C in ((256, 5, 2, 2), (128, 7, 4, 1)):
+                outs = []
+                for sign in (-1, 1):
+                    _native.set_fused_cascade_tuning(vpt, sign * span)
+                    r = fused(graph(p, pan=p['pan'] if C == 2 else None), C)
+                    outs.append(np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(K * N, N, 2).cpu().numpy()]))
+                assert np.isfinite(outs[1]).all() and np.array_equal(outs[0], outs[1]), (V, vpt, N, K, span, C)
+    finally:
+        _native.set_fused_cascade_tuning()
+
+
 def test_other_context_lengths_through_the_c_abi(monkeypatch):
     """the reference's context is 100 frames (fx.py:82-83); the entry point takes it as an argument, and the kernel's
     restarts (running chain minus A^ctx times its state ctx rows ago) must hold for any: 1, 37, 255 of a 256-frame block

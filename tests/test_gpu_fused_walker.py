@@ -292,6 +292,28 @@ def test_mix_matrix_sink_equals_mix_matrix_over_the_stored_chain(kind):
             assert maxerr(closed, f32(ref)) < 2e-6 * scale, (V, N, K, pos, span)
 
 
+def test_tile_sum_inside_the_kernel_equals_the_second_launch_bit_for_bit():
+    """the closed-form bus kernel adds its voice tiles itself when they are 1, 2 or 4 (the waves of a span group then sit
+    in one workgroup; sig_bus::sum_tiles_in_workgroup) and leaves them to partials_kernel otherwise: the same additions
+    in the same order, so the same bits -- for every tile count, batch lengths that are not a multiple of the span
+    (workgroups with idle waves), mono and stereo, short first contexts"""
+    from signals_amd import _native
+    try:
+        for V, vpt, tiles in ((64, 1, 1), (100, 1, 2), (256, 1, 4), (1024, 8, 2), (520, 2, 5), (192, 1, 3)):
+            assert -(-V // (64 * vpt)) == tiles
+            for N, K, span, pos, C in ((256, 7, 4, 0, 2), (128, 5, 2, 37, 1), (256, 9, 8, 4096, 2), (64, 3, 1, 100, 1)):
+                p = params(V, 70 + V + N)
+                geometry(vpt, span, steady=2)                # tiles added by partials_kernel
+                two = run_bus('Sine', 'lp', p, pos, N, K, C=C)
+                geometry(vpt, span, steady=1)                # ... by the kernel itself where it can
+                one = run_bus('Sine', 'lp', p, pos, N, K, C=C)
+                assert np.isfinite(one).all() and np.array_equal(one, two), (V, vpt, N, K, span, pos, C)
+        ref = oracle_chain('Sine', 'lp', p, pos, N, K).sum(axis=1, keepdims=True)      # (the last case is mono)
+        assert C == 1 and maxerr(one, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max())
+    finally:
+        geometry(0, 0, steady=-1)
+
+
 def test_closed_form_vs_walker_over_random_parameter_draws():
     """40 random draws of (V, N, K, position, filter type, bus width, geometry) with log-uniform oscillator
     frequencies (8 Hz .. 11.9 kHz, either sign) and cutoffs (20 Hz .. 23 kHz): the closed form and the row-by-row

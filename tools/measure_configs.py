@@ -40,9 +40,11 @@ def run(name, build, V, steps=10):
     timer = KernelTimer()
     r = BatchRenderer(node, channels, RATE, timer=timer)
     pos = 0
-    for _ in range(2):
+    t_end = time.perf_counter() + 0.2                     # clocks up (they take ~30 ms of load to settle)
+    while time.perf_counter() < t_end:
         r.render(pos, N, K); pos += N * K
-    torch.cuda.synchronize(); timer.reset()
+        torch.cuda.synchronize()
+    timer.reset()
     t0 = time.perf_counter()
     for _ in range(steps):
         r.render(pos, N, K); pos += N * K
