@@ -259,7 +259,7 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
         p = cfg.c5_params(V)
         steps = steps or 100
         node, workload = cfg.c5_graph(p), f'C5: {V}-voice Sine->LowPass->MixMatrix(64x64), 48 kHz, {N}-frame blocks, {K} blocks per batch'
-    timer = KernelTimer()
+    timer = KernelTimer(sample_every=8)                  # (an event pair around EVERY launch costs the stream ~10 % at these launch lengths)
     r = BatchRenderer(node, channels, RATE, timer=timer)
     first = r.render(0, N, K)
     if name == 'C3':
@@ -390,7 +390,8 @@ def main():
     def measure(fuse: bool, steps: int, warmup: int, sustained_s: float = 0.0) -> dict:
         """W untimed + exactly `steps` timed batches of this rank's 1024-voice graph (+ bus reduce); then, optionally,
         the same steps for `sustained_s` more seconds"""
-        timer = None if args.no_kernel_timing else KernelTimer()
+        # fused schedule: one ~200-us launch per step -- every 8th is bracketed by HIP events; node-materialised: all of them
+        timer = None if args.no_kernel_timing else KernelTimer(sample_every=8 if fuse else 1)
         renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
                                             rate=RATE, timer=timer, fuse=fuse)
         assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
