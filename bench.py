@@ -255,7 +255,7 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
         steps = steps or 30
         node, workload = cfg.c3_graph(p), f'C3: {V}-voice Sawtooth->LowPass->LowPass->(x ADSR)->SumBus(mono), 48 kHz, {N}-frame blocks, {K} blocks per batch'
     else:
-        V, channels, N, K = 4096, 4096, 256, 64
+        V, channels, N, K = 4096, 4096, 256, 256             # 268 M voice-samples (1 GiB of mixed rows) per batch
         p = cfg.c5_params(V)
         steps = steps or 100
         node, workload = cfg.c5_graph(p), f'C5: {V}-voice Sine->LowPass->MixMatrix(64x64), 48 kHz, {N}-frame blocks, {K} blocks per batch'

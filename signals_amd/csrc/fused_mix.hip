@@ -147,7 +147,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int launch_steady_mix(const FusedArgs& a_, bool gain, hipStream_t stream)
 {
     FusedArgs a = a_;
-    if (a.span <= 0) a.span = (a.voice_tiles * (int64_t)a.K >= 4096) ? 2 : 1;     // two waves per SIMD when the launch is large enough
+    if (a.span <= 0) {
+        // Blocks per wave: every wave derives its 64 voices' constants and splits the matrix first (~7000 cycles, about two
+        // 32-row tiles' worth), so spans grow while the launch still has two waves for every SIMD (the kernel's occupancy)
+        a.span = 1;
+        while (a.span < 8 && (int64_t)a.voice_tiles * ((a.K + 2 * a.span - 1) / (2 * a.span)) >= 2048) a.span *= 2;
+    }
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     if (gain) fused_steady_mix_kernel<true><<<(unsigned)nwg, 256, 0, stream>>>(a);

@@ -215,7 +215,7 @@ def test_config5_full_size_fused_equals_two_launches():
     from signals_amd.engine import BatchRenderer
     outs = {}
     for fuse in (True, False):
-        mm, channels, n, k, _ = mc.c5(4096)
+        mm, channels, n, k, _ = mc.c5(4096, 64)
         outs[fuse] = BatchRenderer(mm, channels, RATE, fuse=fuse).render(0, n, k)
     assert outs[True].shape == (256 * 64, 4096) and bool(torch.isfinite(outs[True]).all())
     assert float((outs[True].double() - outs[False].double()).abs().max()) < 2e-6

@@ -25,9 +25,9 @@ def c3(V):
     return cfg.c3_graph(cfg.c3_params(V)), 1, 1024, 1024, ALGO
 
 
-def c5(V):
+def c5(V, K=256):
     """Sine -> LowPass -> MixMatrix(64x64), V = 4096, N = 256"""
-    return cfg.c5_graph(cfg.c5_params(V)), V, 256, 64, ALGO
+    return cfg.c5_graph(cfg.c5_params(V)), V, 256, K, ALGO
 
 
 ALGO = {'osc_bank': 4, 'biquad_coldstart': 8, 'adsr': 4, 'adsr_apply': 8, 'fused_osc_biquad': 4, 'elementwise': 12, 'sum_bus': 4,
