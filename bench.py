@@ -473,12 +473,13 @@ def main():
                                                'wave-instruction counted at 2.4 GHz (the chip holds ~1.9 GHz under f64 load), i.e. '
                                                '30.8 T instr-lanes/s is what this instruction mix can reach at all'},
                     'path': 'closed form: steady-state sinusoid + homogeneous transient per block, no warm-up rows '
-                            '(fused_steady_bus_kernel); only constant-parameter Sine->LowPass|HighPass->[Gain]->SumBus takes it: '
-                            'other oscillators run the span walker (~2.0 T voice-samples/s), interposed effects or modulated '
-                            'controls run per-node kernels' if closed else 'span walker (fused_walk_kernel)',
-                    'launches': 'avg_launch_ms brackets everything sig_fused_voice_bus enqueues: the chain kernel and the tile sum '
-                                '(sig_bus::partials_kernel), plus steady_prep_kernel on the calls where the per-voice constants '
-                                "change; the chain kernel's own duration is in profiles/*_kernel_stats.csv"})
+                            '(fused_steady_bus_kernel); constant-parameter Sine->LowPass|HighPass->[Gain]->SumBus takes it; other '
+                            'oscillators, per-block (LFO) cutoff / gain rows and two-oscillator voices run the span walker in one '
+                            'launch too (1.2-2.5 T voice-samples/s), anything else per-node kernels' if closed else 'span walker (fused_walk_kernel)',
+                    'launches': 'avg_launch_ms is the HIP-event time of every 8th launch of the timed steps (bracketing all of them '
+                                'cost the stream 12 %): one kernel per batch -- it adds its two voice tiles itself '
+                                '(sig_bus::sum_tiles_in_workgroup) -- plus steady_prep_kernel on the calls where the per-voice '
+                                "constants change; the kernel's duration under the profiler is in profiles/*_kernel_stats.csv"})
             else:
                 res['roofline'] = hbm_roofline(kernels, dom, pmc_traffic(fam))
             res['kernels'] = kernels
