@@ -9,12 +9,14 @@
 namespace sig_fused {
 namespace {
 
-// The closed form feeding the MixMatrix sink (BASELINE config 5, Sine): one voice per lane, a wave = one 64-voice
-// matrix group over `span` blocks.  Per stored sample 1 (steady two-term recurrence) + 1 (scale) + a conversion, plus 3
-// while the wave's slowest voice still carries its homogeneous part, instead of the walker's 10.45 -- so the launch
-// costs little more than its 64 MFMAs per 32 rows (f64 vector work and the matrix pipe do not overlap on a SIMD).  The
-// per-voice constants are derived by each wave for its own 64 voices (no workspace in this entry point).  Waves with a
-// voice outside the closed form's range walk their blocks row by row with the exact phase.
+// One voice per lane, a wave = one 64-voice matrix group over `span` blocks.  Per stored sample 1 (steady two-term
+// recurrence; the output scale is folded into its two seeds) + a conversion, plus 3 while the wave's slowest voice still
+// carries its homogeneous part, instead of the walker's 10.45; every 32 rows go through sig_mix::Sink (bf16 MFMAs) while
+// the next 32 are produced into the wave's second LDS buffer.  Two waves per SIMD (the sink's matrix operands take 96
+// VGPRs).  Measured by leaving parts out (config 5): stores ~22 us, MFMAs ~28 us, vector work ~21 us, per-wave set-up
+// ~6 us of ~75 -- they add; the stores (3.6-4.4 TB/s) are the part nearest a roof.  The per-voice constants are derived
+// by each wave for its own 64 voices (no workspace in this entry point).  Waves with a voice outside the closed form's
+// range walk their blocks row by row with the exact phase.
 template <bool GAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_steady_mix_kernel(FusedArgs a)
 {
