@@ -263,7 +263,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 #pragma unroll
                 for (int i = 0; i < VPT; ++i) {
                     const double t = t_s * hz[i] + ph[i];
-                    x[i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+                    x[i] = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave_fused<KIND>(t);
                 }
             }
             if constexpr (ROWS) {
@@ -275,9 +275,9 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
                         double b;
                         switch (a.kind2) {                                     // wave-uniform
                             case SIG_OSC_SINE: b = (double)sig_osc::osc_sine_f32(t); break;
-                            case SIG_OSC_SQUARE: b = sig_osc::osc_square(t); break;
-                            case SIG_OSC_SAWTOOTH: b = sig_osc::osc_sawtooth(t); break;
-                            default: b = sig_osc::osc_triangle(t); break;
+                            case SIG_OSC_SQUARE: b = sig_osc::osc_square_fract(t); break;
+                            case SIG_OSC_SAWTOOTH: b = sig_osc::osc_sawtooth_fract(t); break;
+                            default: b = sig_osc::osc_triangle_fract(t); break;
                         }
                         x[i] = (a.pair_op == 1) ? mx[i] * x[i] + (1.0 - mx[i]) * b : x[i] * b;
                     }
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256) void fused_scan_kernel(FusedArgs a)
         const int r = lane * L + k;
         const bool valid = (k < L) && (r < total);
         const double t = (double)(n0 + r) / a.rate * hz + ph;                  // osc.py:32, same operator order
-        double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave<KIND, double>(t);
+        double x = (KIND == SIG_OSC_SINE) ? (double)sig_osc::osc_sine_f32(t) : sig_osc::osc_wave_fused<KIND>(t);
         x = valid ? x : 0.0;
         const double y = fma(q.b0, x, z0);
         const double nz0 = fma(q.b1, x, fma(-q.a1, y, z1));

@@ -110,10 +110,29 @@ __device__ __forceinline__ double osc_sawtooth_fract(double t) {
     return fma(__builtin_amdgcn_fract(t - 0.5), 2.0, -1.0);
 }
 
+// Square for the fused kernels: sign(d), d = 0.5 - m, as copysign(1, d) (one v_and_or_b32 on the high word) kept where
+// |d| > 0 and d itself (a zero, or a NaN from NaN parameters) elsewhere -- one compare and two 32-bit selects instead of
+// np.sign's two compares and four.  Same values as osc_square except in v_fract_f64's corner (see above), where both
+// answer -1.
+__device__ __forceinline__ double osc_square_fract(double t) {
+    const double d = 0.5 - __builtin_amdgcn_fract(t);
+    const double one = __hiloint2double((int)(((unsigned)__double2hiint(d) & 0x80000000u) | 0x3ff00000u), 0);
+    return (fabs(d) > 0.0) ? one : d;
+}
+
+// Triangle for the fused kernels.  The reference's (4 mod(u, 1/2) - 1) * sign(mod(u, 1) - 1/2), u = t - 1/4, is
+// 4 |m - 1/2| - 1 with m = mod(u, 1), in one rounding of the same real number on either branch (m - 1/2 and mod(u, 1/2)
+// are exact), except AT m = 1/2, where sign(0) makes it a zero: kept.  5 instructions + the zero fix instead of 15.
+__device__ __forceinline__ double osc_triangle_fract(double t) {
+    const double d = __builtin_amdgcn_fract(t - 0.25) - 0.5;
+    const double r = fma(fabs(d), 4.0, -1.0);
+    return (d == 0.0) ? 0.0 : r;
+}
+
 template <int KIND> __device__ __forceinline__ double osc_wave_fused(double t) {
-    if (KIND == SIG_OSC_SQUARE) return osc_square(t);
+    if (KIND == SIG_OSC_SQUARE) return osc_square_fract(t);
     if (KIND == SIG_OSC_SAWTOOTH) return osc_sawtooth_fract(t);
-    if (KIND == SIG_OSC_TRIANGLE) return osc_triangle(t);
+    if (KIND == SIG_OSC_TRIANGLE) return osc_triangle_fract(t);
     return osc_sine(t);
 }
 
