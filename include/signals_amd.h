@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 4
+#define SIG_ABI_VERSION 5
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -197,7 +197,7 @@ int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t posi
  * every block its own filter design and gain.  cutoff_rows / gain_rows: 1 (one row for the launch) or nblocks (row b
  * for block b, rows contiguous: row b of a per-voice parameter starts at + b * voices, of a broadcast one at + b).
  * Always the row-by-row span walker (the next block's warm-up chain runs with the next block's design); gain may be
- * NULL; bus_channels 1 or 2.  hertz and phase stay one row: a modulated oscillator is not position-pure. */
+ * NULL; bus_channels 1 or 2.  hertz and phase stay one row here (sig_fused_*_fm below takes rows for them too). */
 int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
                               int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                               const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
@@ -211,6 +211,30 @@ int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t 
                              const double* gain, int32_t gain_stride, int32_t gain_rows,
                              const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
                              double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
+/* ... and with hertz and phase read per block as well: block-rate frequency / phase modulation (Osc._eval reads both
+ * ports with forward_at_block_rate, osc.py:28-30).  hertz_rows / phase_rows: 1 or nblocks, rows laid out like cutoff's.
+ * The reference's oscillators keep their previous block (BlockCachingEmitter, chain/__init__.py:424-442), so the context
+ * rows a filter sees in front of block b are block b - 1's samples, made with parameter row b - 1: the walker's
+ * warm-up chain already runs on the samples at hand.  For the launch's first block that row is *_hist (one (1,V)|(1,1)
+ * row, same stride; non-NULL marks the parameter as modulated -- also in a one-block launch, whose single row still has a
+ * different row in front; required when the matching *_rows > 1): the previous batch's last row on a continuing stream, the
+ * controls evaluated at position - min(context, position) on a fresh graph.  Sine then takes the exact per-row phase. */
+int sig_fused_osc_biquad_fm(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                            int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                            const double* hertz, int32_t hertz_stride, int32_t hertz_rows, const double* hertz_hist,
+                            const double* phase, int32_t phase_stride, int32_t phase_rows, const double* phase_hist,
+                            const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                            const double* gain, int32_t gain_stride, int32_t gain_rows,
+                            float* out, int64_t out_ld, int32_t* status, void* stream);
+int sig_fused_voice_bus_fm(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                           int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                           const double* hertz, int32_t hertz_stride, int32_t hertz_rows, const double* hertz_hist,
+                           const double* phase, int32_t phase_stride, int32_t phase_rows, const double* phase_hist,
+                           const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                           const double* gain, int32_t gain_stride, int32_t gain_rows,
+                           const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                           double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
 
 /* The same two entry points for a filter that reads TWO oscillators through an element-wise node: pair_op 1 =
  * Mix(A, B, mix): mix * A + (1 - mix) * B with mix one (1,V)|(1,1) row (Mix._eval, fx.py:35-40); pair_op 2 =

@@ -20,7 +20,7 @@ OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
 FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 SINE_FAST_MAX_CYCLES = 2.0 ** 26     # sig_osc.h kSineFastMaxT: |t| up to which the fused Sine kernels advance the phase incrementally
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
@@ -31,7 +31,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_latency_voice_bus_workspace', 'sig_fused_voice_bus_prepared', 'sig_fused_voice_consts_size',
            'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
-           'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus')
+           'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
+           'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm')
 
 
 class NativeError(RuntimeError):
@@ -133,6 +134,12 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus_rows.restype = ctypes.c_int
         L.sig_fused_voice_bus_rows.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                dp, i32, dp, i32, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_fused_osc_biquad_fm.restype = ctypes.c_int
+        L.sig_fused_osc_biquad_fm.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                              dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, vp, i64, vp, vp]
+        L.sig_fused_voice_bus_fm.restype = ctypes.c_int
+        L.sig_fused_voice_bus_fm.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
+                                             dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
         L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                 dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
@@ -550,12 +557,57 @@ def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: in
                hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
                out: torch.Tensor, bus_gains: torch.Tensor | None = None, bus: bool = False,
                workspace: torch.Tensor | None = None, status: torch.Tensor | None = None,
-               pair: tuple | None = None) -> torch.Tensor:
+               pair: tuple | None = None, hertz_hist: torch.Tensor | None = None,
+               phase_hist: torch.Tensor | None = None) -> torch.Tensor:
     """[gain *] Filter(Osc) with cutoff / gain rows read per block: out (nblocks*block_frames, voices) f32
     (sig_fused_osc_biquad_rows), or with `bus` the sum over voices weighted by bus_gains, out (.., C) (sig_fused_voice_bus_rows).
     `pair` = (op, kind2, hertz2, phase2, mix): the filter reads Mix (op 'Mix') or RingMod (op 'RingMod') of the oscillator
-    above and a second one (sig_fused_osc_pair_biquad / sig_fused_voice_pair_bus)."""
-    _gpu(hertz, phase, cutoff, gain, out, bus_gains, workspace, status, *((pair[2], pair[3], pair[4]) if pair else ()))
+    above and a second one (sig_fused_osc_pair_biquad / sig_fused_voice_pair_bus).
+    hertz / phase with nblocks rows: block-rate FM (sig_fused_osc_biquad_fm / sig_fused_voice_bus_fm); `hertz_hist` /
+    `phase_hist` = the (1, .) row in front of the launch (the previous block's, whose samples are block 0's context)."""
+    _gpu(hertz, phase, cutoff, gain, out, bus_gains, workspace, status, hertz_hist, phase_hist,
+         *((pair[2], pair[3], pair[4]) if pair else ()))
+    fm = hertz_hist is not None or phase_hist is not None or hertz.shape[0] > 1 or (phase is not None and phase.shape[0] > 1)
+    if fm:
+        if pair is not None:
+            raise NativeError('block-rate FM and a second oscillator: no fused entry point')
+        hp, hs, hrows = _param_rows(hertz, 'hertz', voices, nblocks)
+        pp, ps, prows = _param_rows(phase, 'phase', voices, nblocks)
+
+        def hist(t, like, rows, what):
+            if t is None and rows == 1:
+                return None
+            if t is None or t.dtype != torch.float64 or tuple(t.shape) != (1, like.shape[1]) or not t.is_contiguous():
+                raise NativeError(f'{what}: the row in front of the launch is float64 (1, {like.shape[1]})')
+            return t.data_ptr()
+        hh, ph_ = hist(hertz_hist, hertz, hrows, 'hertz_hist'), hist(phase_hist, phase, prows, 'phase_hist') if phase is not None else None
+        cp, cs, crows = _param_rows(cutoff, 'cutoff', voices, nblocks)
+        gp, gs, grows = _param_rows(gain, 'gain', voices, nblocks)
+        st = status.data_ptr() if status is not None else None
+        _audio(out, 'fused rows out')
+        if out.dtype != torch.float32 or out.shape[0] != block_frames * nblocks:
+            raise NativeError(f'fused rows out must be float32 ({block_frames * nblocks}, .), got {tuple(out.shape)} {out.dtype}')
+        head = (OSC_KINDS[kind], FILT_TYPES[btype], rate, position, block_frames, nblocks, context, voices,
+                hp, hs, hrows, hh, pp, ps, prows, ph_, cp, cs, crows, gp, gs, grows)
+        if not bus:
+            if out.shape[1] != voices:
+                raise NativeError(f'fused rows out has {out.shape[1]} channels for {voices} voices')
+            _check(lib().sig_fused_osc_biquad_fm(*head, out.data_ptr(), out.stride(0), st, _stream(out)), 'sig_fused_osc_biquad_fm')
+            return out
+        C = out.shape[1]
+        bp, bld = None, 0
+        if bus_gains is not None:
+            if bus_gains.dtype != torch.float64 or bus_gains.shape != (C, voices) or bus_gains.stride(1) != 1:
+                raise NativeError(f'bus gains must be float64 ({C},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+            bp, bld = bus_gains.data_ptr(), bus_gains.stride(0)
+        elif C != 1:
+            raise NativeError('a bus without gains is mono')
+        need = lib().sig_fused_voice_bus_workspace(voices, out.shape[0], C)
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+        _check(lib().sig_fused_voice_bus_fm(*head, bp, bld, C, workspace.data_ptr(), out.data_ptr(), out.stride(0), st, _stream(out)),
+               'sig_fused_voice_bus_fm')
+        return out
     _audio(out, 'fused rows out')
     rows = out.shape[0]
     if out.dtype != torch.float32 or rows != block_frames * nblocks:

@@ -138,12 +138,17 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     for (int i = 0; i < VPT; ++i) z0[i] = z1[i] = 0.0;
 
     // hertz / phase of the lane's voices (re-read where needed rather than kept live across the row loops)
-    auto load_hz_ph = [&](double (&hz)[VPT], double (&ph)[VPT]) {
+    // ROWS with hertz_rows / phase_rows > 1: row `blk` of the launch (-1: the row in front of it, *_hist)
+    const bool fm = ROWS && (a.hertz_hist || a.phase_hist);                    // (a one-block launch has one row, and still a row in front)
+    auto load_hz_ph = [&](double (&hz)[VPT], double (&ph)[VPT], int64_t blk = 0) {
+        const double* hp = a.hertz; const double* pp = a.phase;
+        if (ROWS && a.hertz_hist) hp = (blk < 0) ? a.hertz_hist : a.hertz + (a.hertz_rows > 1 ? blk * (int64_t)(a.hs ? a.voices : 1) : 0);
+        if (ROWS && a.phase_hist) pp = (blk < 0) ? a.phase_hist : a.phase + (a.phase_rows > 1 ? blk * (int64_t)(a.ps ? a.voices : 1) : 0);
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = (v0 + i < a.voices) ? v0 + i : vc;
-            hz[i] = a.hertz[(int64_t)v * a.hs];
-            ph[i] = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+            hz[i] = hp[(int64_t)v * a.hs];
+            ph[i] = pp ? pp[(int64_t)v * a.ps] : 0.0;
         }
     };
 
@@ -169,7 +174,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             sdl[i] = 2.0 * sh * sin2pi(f0 + 0.5 * dr + 0.25);                  // x_1 - x_0
             snm[i] = -4.0 * sh * sh;
         }
-        fast = __all(small);
+        fast = __all(small) && !fm;                                            // (the incremental phase assumes one hertz for the span)
     }
 
     float* dst = (BUS || MIX) ? nullptr : a.out + vc;                          // row index = frame - position
@@ -222,12 +227,12 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     };
 
     // `count` consecutive rows from n_cur on; OUT rows go to output rows out_row, out_row + 1, ...
-    auto walk = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, auto fast_tag) {
+    auto walk = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, auto fast_tag, int64_t blk) {
         constexpr bool OUT = decltype(out_tag)::value, FAST = decltype(fast_tag)::value;
         double hz[VPT], ph[VPT], q_lane = 0.0;
         int64_t qbase = 0;
         bool q_valid = false;
-        if (!FAST) load_hz_ph(hz, ph);
+        if (!FAST) load_hz_ph(hz, ph, blk);
         // second oscillator of a Mix / RingMod source (ROWS kernels only; its waveform is a wave-uniform run-time switch)
         const bool paired = ROWS && a.pair_op != 0;
         double hz2[ROWS ? VPT : 1], ph2[ROWS ? VPT : 1], mx[ROWS ? VPT : 1];
@@ -346,22 +351,23 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         if (have) folded.finish(pend, pend_row, R);
         while (done < count) single();
     };
-    auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag) {
-        if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{});
-        else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{});
+    // `blk`: the block whose hertz / phase rows these rows were made with (only read under block-rate FM)
+    auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, int64_t blk) {
+        if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{}, blk);
+        else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{}, blk);
     };
 
-    walk_any(c0, 0, z0, z1, std::false_type{}, std::false_type{});             // warm-up of the span's first block
+    walk_any(c0, 0, z0, z1, std::false_type{}, std::false_type{}, b_first - 1);   // warm-up of the span's first block: the previous block's samples
     for (int bi = 0; bi < nb; ++bi) {
         const int64_t orow = (b_first + bi) * a.N;
         const int tail = (bi + 1 < nb) ? a.ctx : 0;                            // rows that also warm the next block up (N >= ctx)
-        walk_any(a.N - tail, orow, z0, z1, std::true_type{}, std::false_type{});
+        walk_any(a.N - tail, orow, z0, z1, std::true_type{}, std::false_type{}, b_first + bi);
         if (tail) {
             double w0[VPT], w1[VPT];                                           // the next block's chain, from zero state
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { w0[i] = 0.0; w1[i] = 0.0; }
             if constexpr (ROWS) design_block(b_first + bi + 1, wna1, wna2, [&](int ch, int i, double w) { wwt[ch][i] = w; });
-            walk_any(tail, orow + a.N - tail, w0, w1, std::true_type{}, std::true_type{});
+            walk_any(tail, orow + a.N - tail, w0, w1, std::true_type{}, std::true_type{}, b_first + bi);
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { z0[i] = w0[i]; z1[i] = w1[i]; }
             if constexpr (ROWS) {
@@ -1112,6 +1118,15 @@ bool pair_ok(const PairSource& p) {
     return p.op == 0 || ((p.op == 1 || p.op == 2) && p.kind2 >= SIG_OSC_SINE && p.kind2 <= SIG_OSC_TRIANGLE && p.hertz2 &&
                          (p.hs2 | 1) == 1 && (p.ps2 | 1) == 1 && (p.ms | 1) == 1 && (p.op == 2 || p.mix));
 }
+// block-rate FM (sig_fused_*_fm): hertz / phase rows per block + the row in front of the launch
+struct FmSource { int hertz_rows = 1, phase_rows = 1; const double* hertz_hist = nullptr; const double* phase_hist = nullptr; };
+bool fm_ok(const FmSource& f, int nblocks, const double* phase) {
+    return (f.hertz_rows == 1 || (f.hertz_rows == nblocks && f.hertz_hist)) &&
+           (f.phase_rows == 1 || (f.phase_rows == nblocks && f.phase_hist)) && (!f.phase_hist || phase);
+}
+void set_fm(FusedArgs& a, const FmSource& f) {
+    a.hertz_rows = f.hertz_rows; a.phase_rows = f.phase_rows; a.hertz_hist = f.hertz_hist; a.phase_hist = f.phase_hist;
+}
 void set_pair(FusedArgs& a, const PairSource& p) {
     a.pair_op = p.op; a.kind2 = p.kind2; a.hertz2 = p.hertz2; a.hs2 = p.hs2; a.phase2 = p.phase2; a.ps2 = p.ps2;
     a.mixrow = p.mix; a.ms = p.ms;
@@ -1121,11 +1136,11 @@ int fused_chain_general(int osc_kind, int filt_type, int32_t rate, int64_t posit
                         int32_t context, int32_t voices, const double* hertz, int32_t hertz_stride, const double* phase,
                         int32_t phase_stride, const PairSource& pair, const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
                         const double* gain, int32_t gain_stride, int32_t gain_rows, float* out, int64_t out_ld, int32_t* status,
-                        void* stream)
+                        void* stream, const FmSource& fm = FmSource{})
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices && pair_ok(pair));
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices && pair_ok(pair) && fm_ok(fm, nblocks, phase));
     SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
     SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
     if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
@@ -1134,6 +1149,7 @@ int fused_chain_general(int osc_kind, int filt_type, int32_t rate, int64_t posit
                 out, out_ld, 0, status};
     a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
     set_pair(a, pair);
+    set_fm(a, fm);
     return dispatch_rows_kind<0>(osc_kind, a, BusArgs{nullptr, 0, nullptr, 0}, out, out_ld, static_cast<hipStream_t>(stream));
 }
 
@@ -1141,11 +1157,12 @@ int fused_bus_general(int osc_kind, int filt_type, int32_t rate, int64_t positio
                       int32_t context, int32_t voices, const double* hertz, int32_t hertz_stride, const double* phase,
                       int32_t phase_stride, const PairSource& pair, const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
                       const double* gain, int32_t gain_stride, int32_t gain_rows, const double* bus_gains, int64_t bus_gains_ld,
-                      int32_t bus_channels, double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+                      int32_t bus_channels, double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
+                      const FmSource& fm = FmSource{})
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels && pair_ok(pair));
+    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels && pair_ok(pair) && fm_ok(fm, nblocks, phase));
     SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
     SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
     SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
@@ -1155,6 +1172,7 @@ int fused_bus_general(int osc_kind, int filt_type, int32_t rate, int64_t positio
                 nullptr, 0, 0, status};
     a.cutoff_rows = cutoff_rows; a.gain_rows = gain_rows;
     set_pair(a, pair);
+    set_fm(a, fm);
     BusArgs bus{bus_gains, bus_gains_ld, workspace, (int64_t)block_frames * nblocks};
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (bus_channels) {
@@ -1220,6 +1238,34 @@ extern "C" int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rat
     return fused_bus_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
                              phase_stride, PairSource{}, cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, bus_gains,
                              bus_gains_ld, bus_channels, workspace, out, out_ld, status, stream);
+}
+
+extern "C" int sig_fused_osc_biquad_fm(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                       int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                       const double* hertz, int32_t hertz_stride, int32_t hertz_rows, const double* hertz_hist,
+                                       const double* phase, int32_t phase_stride, int32_t phase_rows, const double* phase_hist,
+                                       const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                       const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                       float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    return fused_chain_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                               phase_stride, PairSource{}, cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, out, out_ld,
+                               status, stream, FmSource{hertz_rows, phase_rows, hertz_hist, phase_hist});
+}
+
+extern "C" int sig_fused_voice_bus_fm(int osc_kind, int filt_type, int32_t rate, int64_t position,
+                                      int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
+                                      const double* hertz, int32_t hertz_stride, int32_t hertz_rows, const double* hertz_hist,
+                                      const double* phase, int32_t phase_stride, int32_t phase_rows, const double* phase_hist,
+                                      const double* cutoff, int32_t cutoff_stride, int32_t cutoff_rows,
+                                      const double* gain, int32_t gain_stride, int32_t gain_rows,
+                                      const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                                      double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream)
+{
+    return fused_bus_general(osc_kind, filt_type, rate, position, block_frames, nblocks, context, voices, hertz, hertz_stride, phase,
+                             phase_stride, PairSource{}, cutoff, cutoff_stride, cutoff_rows, gain, gain_stride, gain_rows, bus_gains,
+                             bus_gains_ld, bus_channels, workspace, out, out_ld, status, stream,
+                             FmSource{hertz_rows, phase_rows, hertz_hist, phase_hist});
 }
 
 extern "C" int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const int64_t* position_dev,

@@ -24,6 +24,12 @@ struct FusedArgs {
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
     int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
     int cutoff_rows = 1, gain_rows = 1;      // > 1: one (1,V)|(1,1) parameter row PER BLOCK (sig_fused_*_rows), row b at + b * (stride ? voices : 1)
+    // sig_fused_*_fm: hertz / phase also per block (block-rate FM, osc.py:28-30).  The reference's oscillators keep their
+    // previous block (BlockCachingEmitter), so the context rows in front of block b are block b - 1's samples, made with row
+    // b - 1; for the launch's first block that row is *_hist (the previous batch's last row on a continuing stream, the
+    // controls at position - min(context, position) on a fresh graph); a non-null *_hist is what marks the parameter as modulated
+    int hertz_rows = 1, phase_rows = 1;
+    const double* hertz_hist = nullptr; const double* phase_hist = nullptr;
     // sig_fused_*_pair: the filter reads Mix(A, B, mix) (pair_op 1) or RingMod(A, B) (pair_op 2) of TWO oscillators
     int pair_op = 0, kind2 = 0;
     const double* hertz2 = nullptr; int hs2 = 0; const double* phase2 = nullptr; int ps2 = 0; const double* mixrow = nullptr; int ms = 0;

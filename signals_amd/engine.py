@@ -836,10 +836,13 @@ class _VoiceChain:
         self.ports = [src.hertz, src.phase, filt.cutoff] + self.gain_ports
         self.involved = [n for n in (src, filt, gain_node, bus_node, pre_gain, *(pair or ())) if n is not None]
         self.kind, self.btype = src.kind(), str(filt.type())
-        self.modulated = any(not _ctl_const(p) for p in [filt.cutoff] + self.gain_ports)   # per-block parameter rows
-        self.general = self.modulated or pair is not None          # the walker's general entry points (sig_fused_*_rows / *_pair)
+        self.fm = not (_ctl_const(src.hertz) and _ctl_const(src.phase))   # block-rate frequency / phase modulation (osc.py:28-30)
+        self.hist_rows = (None, None)                              # hertz / phase of the block in front of the batch, as resolve() found them
+        self.modulated = self.fm or any(not _ctl_const(p) for p in [filt.cutoff] + self.gain_ports)   # per-block parameter rows
+        self.general = self.modulated or pair is not None          # the walker's general entry points (sig_fused_*_rows / *_pair / *_fm)
         source = self.kind if pair is None else f'{type(pair[0]).__name__}({self.kind},{pair[1].kind()})'
-        self.tag = f'{source},{self.btype}{",gain" if self.gain_ports else ""}{",per-block" if self.modulated else ""}'
+        self.tag = (f'{source},{self.btype}{",gain" if self.gain_ports else ""}{",per-block" if self.modulated else ""}'
+                    f'{",fm" if self.fm else ""}')
         if pair is not None:
             self.ports += [pair[1].hertz, pair[1].phase] + ([pair[0].mix] if isinstance(pair[0], fx.Mix) else [])
 
@@ -884,6 +887,8 @@ class _VoiceChain:
                 pair, src = (src, right), left
         if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
             return None
+        if pair is not None and not (_ctl_const(src.hertz) and _ctl_const(src.phase)):
+            return None                                             # (two oscillators AND block-rate FM: per node)
         chain = cls(batch, src, filt, gain_node, bus_node, channels, pre_gain, pair)
         controls = chain.resolve()
         if controls is None or not chain.widths_ok(controls):
@@ -898,7 +903,19 @@ class _VoiceChain:
         if not all(n.get_state().enabled for n in self.involved):
             return None
         try:
-            rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]          # a modulated oscillator is not position-pure
+            if self.fm:
+                # hertz / phase driven by a block-rate signal: K rows each, and the row of the block in FRONT of the batch --
+                # the reference's oscillators keep their previous block (BlockCachingEmitter), so block 0's context rows are
+                # that block's samples: the previous batch's last block on a contiguous stream, else the context request
+                # [pos - c, pos) answered as a block of its own (its controls read at pos - c)
+                b, o = self.batch, self.batch.owner
+                rows = [as_control(b._control(p, p.name)) for p in self.ports[:2]]
+                contiguous = o._stream_end == b.pos and bool(o._prev_block_frames) and o._prev_block_frames >= min(CONTEXT, b.pos)
+                q = b.pos - (o._prev_block_frames if contiguous else min(CONTEXT, b.pos))
+                front = _Batch(o, q, max(b.pos - q, 2), 1, False)
+                self.hist_rows = tuple(None if _ctl_const(p) else as_control(front._control(p, p.name)) for p in self.ports[:2])
+            else:
+                rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]
             if self.pair is not None:
                 op, second = self.pair
                 self.pair_rows = (self.batch._control_const(second.hertz, 'hertz'), self.batch._control_const(second.phase, 'phase'),
@@ -1012,7 +1029,8 @@ class _VoiceChain:
             if self.general:
                 return o._launch(name, lambda: _native.fused_rows(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
                                                                   ctl[0], ctl[1], ctl[2], ctl[3], out, status=status,
-                                                                  pair=self.pair_arg()),
+                                                                  pair=self.pair_arg(), hertz_hist=self.hist_rows[0],
+                                                                  phase_hist=self.hist_rows[1]),
                                  units=rows * v)
             return o._launch(name, lambda: _native.fused_osc_biquad(self.kind, self.btype, rate, position, N, K, CONTEXT,
                                                                     ctl[0], ctl[1], ctl[2], ctl[3], out, status=status),
@@ -1068,7 +1086,8 @@ class _VoiceChain:
             return o._launch(f'fused_voice_bus[{self.tag}]',
                              lambda: _native.fused_rows(self.kind, self.btype, rate, b.pos, N, K, CONTEXT, v, controls[0], controls[1],
                                                         controls[2], controls[3], out, bus_gains=pan, bus=True,
-                                                        workspace=o._workspace, status=status, pair=self.pair_arg()),
+                                                        workspace=o._workspace, status=status, pair=self.pair_arg(),
+                                                        hertz_hist=self.hist_rows[0], phase_hist=self.hist_rows[1]),
                              units=rows * v)
         # latency regime: too few (voice, block) chains to fill the chip with serial walks -> the chain runs as a
         # time-parallel prefix scan (sig_fused_osc_biquad picks it) and the bus as its own launch
