@@ -328,6 +328,23 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
         extra['long_batches'] = {'blocks_per_batch': K4, 'value': V * N * K4 * 10 / dt4 / 1e6, 'unit': 'Msamples/s',
                                  'ms_per_step': dt4 / 10 * 1e3, 'steps': 10,
                                  'launch_geometry': dict(zip(('voices_per_lane', 'blocks_per_lane'), _native.fused_cascade_geometry(V, K4)))}
+    if name == 'C5':
+        # BASELINE names this configuration "MFMA fp32": the same launch with the sink on v_mfma_f32_32x32x2_f32 (the default
+        # contracts each float32 as three bfloat16 -- exact products, float32 accumulators, sig_mix_tile.h)
+        _native.set_fused_tuning(0, 0, 3, -1)
+        try:
+            r32 = BatchRenderer(node, channels, RATE)
+            got32 = r32.render(0, N, K)[:N].double().cpu().numpy()
+            ref0 = R.render(cfg.c5_oracle(p), 0, N, V, RATE).astype(np.float32).astype(np.float64)
+            r, keep = r32, r
+            dt32, _ = timed(K, max(steps // 2, 10), N * K)
+            r = keep
+            extra['f32_mfma_sink'] = {'value': V * N * K * max(steps // 2, 10) / dt32 / 1e6, 'unit': 'Msamples/s',
+                                      'ms_per_step': dt32 / max(steps // 2, 10) * 1e3,
+                                      'max_abs_error_block_0': float(np.max(np.abs(got32 - ref0))),
+                                      'instruction': 'v_mfma_f32_32x32x2_f32, 64 per 32-row x 64-voice tile'}
+        finally:
+            _native.set_fused_tuning()
     return {**extra, 'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
             'steps': steps, 'roofline': roof, 'kernels': kernels,
             'max_abs_error': {'per_block': errs, 'max': max(errs.values()), 'full_scale': full_scale,

@@ -375,7 +375,8 @@ int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t voices, int
                              int32_t context, int32_t* voices_per_lane, int32_t* blocks_per_lane, int32_t* closed_form);
 /* Tuning / test hook of the fused entry points: force the voices per lane (0 = heuristic), the blocks per lane
  * (0 = heuristic), the Sine closed form (-1 = heuristic, 0 = off, 1 = on, 2 = on with the voice tiles added by a second
- * launch instead of inside the kernel) and the latency-mode prefix-scan kernel
+ * launch instead of inside the kernel, 3 = on with the MixMatrix sink on the float32 MFMA instead of three-way bfloat16
+ * splits) and the latency-mode prefix-scan kernel
  * (-1 = heuristic, 0 = off, 1 = on).  Process-wide, not thread-safe against concurrent launches; the initial values
  * come from SIG_FUSED_VPT / _SPAN / _STEADY / _SCAN, read once. */
 int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan);

@@ -17,7 +17,7 @@ namespace {
 // ~6 us of ~75 -- they add; the stores (3.6-4.4 TB/s) are the part nearest a roof.  The per-voice constants are derived
 // by each wave for its own 64 voices (no workspace in this entry point).  Waves with a voice outside the closed form's
 // range walk their blocks row by row with the exact phase.
-template <bool GAIN>
+template <bool GAIN, bool F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_steady_mix_kernel(FusedArgs a)
 {
     __shared__ __attribute__((aligned(16))) float lds[4][2 * sig_mix::kTileRows * sig_mix::kLdsStride];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
 
     // MixMatrix sink: rows staged as float32, 32 at a time through the matrix cores (sig_mix_tile.h)
-    sig_mix::Sink sink;
+    sig_mix::SinkT<F32> sink;                                                  // F32: the exact-f32 MFMA (tuning hook; a.steady == 3)
     sink.init(a.mix, ftile, a.out + (int64_t)vt * 64, a.out_ld, b_first * a.N, lane);
     auto stage = [&](double y) { sink.stage((float)y); };
 
@@ -157,8 +157,14 @@ int launch_steady_mix(const FusedArgs& a_, bool gain, hipStream_t stream)
     }
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    if (gain) fused_steady_mix_kernel<true><<<(unsigned)nwg, 256, 0, stream>>>(a);
-    else fused_steady_mix_kernel<false><<<(unsigned)nwg, 256, 0, stream>>>(a);
+    const bool f32 = a.steady == 3;                                            // sig_fused_set_tuning(closed_form = 3)
+    if (gain) {
+        if (f32) fused_steady_mix_kernel<true, true><<<(unsigned)nwg, 256, 0, stream>>>(a);
+        else fused_steady_mix_kernel<true, false><<<(unsigned)nwg, 256, 0, stream>>>(a);
+    } else {
+        if (f32) fused_steady_mix_kernel<false, true><<<(unsigned)nwg, 256, 0, stream>>>(a);
+        else fused_steady_mix_kernel<false, false><<<(unsigned)nwg, 256, 0, stream>>>(a);
+    }
     return sig_launch_status();
 }
 

@@ -759,7 +759,7 @@ int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
 
 // Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
 // _STEADY, _SCAN: read ONCE, when the first launch asks) and tests set them through sig_fused_set_tuning.
-struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1, tile_sum_kernel = 0; };     // 0 / -1 = the launch heuristics decide
+struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1, tile_sum_kernel = 0, mix_f32 = 0; };     // 0 / -1 = the launch heuristics decide
 Tuning& tuning() {
     static Tuning t = [] {
         auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -767,6 +767,7 @@ Tuning& tuning() {
         u.vpt = env("SIG_FUSED_VPT", 0); u.span = env("SIG_FUSED_SPAN", 0);
         u.steady = env("SIG_FUSED_STEADY", -1); u.scan = env("SIG_FUSED_SCAN", -1);
         if (u.steady == 2) { u.steady = 1; u.tile_sum_kernel = 1; }
+        if (u.steady == 3) { u.steady = 1; u.mix_f32 = 1; }
         return u;
     }();
     return t;
@@ -1057,6 +1058,7 @@ int launch_mix(FusedArgs a, hipStream_t stream)
         // (fused_mix.hip; blocks per wave: see launch_steady_mix)
         if (tuning().span == 0) a.span = 0;
         a.voice_tiles = a.voices / SIG_WAVE;
+        a.steady = tuning().mix_f32 ? 3 : 1;
         return launch_steady_mix(a, GAIN, stream);
     }
     return launch_walk<KIND, GAIN, -1>(a, BusArgs{nullptr, 0, nullptr, 0}, 1, stream);
@@ -1348,11 +1350,12 @@ extern "C" int sig_fused_voice_bus_plan(int osc_kind, int64_t position, int32_t 
 
 extern "C" int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane, int32_t closed_form, int32_t scan)
 {
-    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0 && closed_form >= -1 && closed_form <= 2 && scan >= -1);
+    SIG_CHECK_ARG(voices_per_lane >= 0 && blocks_per_lane >= 0 && closed_form >= -1 && closed_form <= 3 && scan >= -1);
     Tuning& t = tuning();
     t.vpt = voices_per_lane; t.span = blocks_per_lane; t.scan = scan;
-    t.steady = (closed_form == 2) ? 1 : closed_form;                           // 2: closed form on, voice tiles added by partials_kernel
+    t.steady = (closed_form == 2 || closed_form == 3) ? 1 : closed_form;       // 2: closed form on, voice tiles added by partials_kernel
     t.tile_sum_kernel = (closed_form == 2) ? 1 : 0;
+    t.mix_f32 = (closed_form == 3) ? 1 : 0;                                    // 3: closed form on, the MixMatrix sink on v_mfma_f32_32x32x2_f32
     return 0;
 }
 

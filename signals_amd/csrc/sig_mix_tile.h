@@ -45,13 +45,26 @@ __device__ __forceinline__ void split8(const float* x, bf16x8 (&f)[3]) {
 // A[row r][k = 8 h + j] and B[k = 8 h + j][col r], j = 0 .. 7.  The k of k-block kb is voice 32 h + 8 kb + j -- any
 // one-to-one assignment serves as long as A and B agree -- so a lane's A fragments are its row's half 32 h .. 32 h + 31
 // (eight ds_read_b128, conflict-free on the padded tile).
-struct Sink {
-    bf16x8 bm[3][2][4];                    // [part of m][column half][k-block]: 96 VGPRs
+// F32 = true: the same sink on v_mfma_f32_32x32x2_f32 (lane l holds A[row l & 31][k = l >> 5] and B[k = l >> 5][col l & 31]; 64
+// of them per tile, the matrix as 64 float VGPRs) -- what mix_matrix.hip issues, kept selectable (sig_fused_set_tuning) so
+// that BASELINE config 5 can also be timed on the instruction its name carries.
+template <bool F32>
+struct SinkT {
+    bf16x8 bm[F32 ? 1 : 3][F32 ? 1 : 2][F32 ? 1 : 4];     // [part of m][column half][k-block]: 96 VGPRs
+    float bmf[F32 ? 2 : 1][F32 ? 32 : 1];                 // F32: M[32 h + ks][32 jt + r]
     float* tile; float* tile_next; float* out; int64_t out_ld, row0; int lane, staged;
 
     __device__ __forceinline__ void init(const float* mix, float* tile_, float* out_, int64_t out_ld_, int64_t first_row, int lane_) {
         tile = tile_; tile_next = tile_ + kTileRows * kLdsStride; out = out_; out_ld = out_ld_; row0 = first_row; lane = lane_; staged = 0;
         const int r = lane & 31, h = lane >> 5;
+        if constexpr (F32) {
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                bmf[0][ks] = mix[(32 * h + ks) * 64 + r];
+                bmf[1][ks] = mix[(32 * h + ks) * 64 + 32 + r];
+            }
+            return;
+        }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -80,12 +93,20 @@ struct Sink {
                 const float4 t = *reinterpret_cast<const float4*>(tile + r * kLdsStride + 32 * h + 8 * kb + 4 * c);
                 x[4 * c] = t.x; x[4 * c + 1] = t.y; x[4 * c + 2] = t.z; x[4 * c + 3] = t.w;
             }
-            bf16x8 ax[3];
-            split8(x, ax);
+            if constexpr (F32) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kTerms[t][0]], bm[kTerms[t][1]][0][kb], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kTerms[t][0]], bm[kTerms[t][1]][1][kb], acc1, 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], bmf[0][8 * kb + j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], bmf[1][8 * kb + j], acc1, 0, 0, 0);
+                }
+            } else {
+                bf16x8 ax[3];
+                split8(x, ax);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kTerms[t][0]], bm[kTerms[t][1]][0][kb], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kTerms[t][0]], bm[kTerms[t][1]][1][kb], acc1, 0, 0, 0);
+                }
             }
             between(kb);
         }
@@ -114,5 +135,6 @@ struct Sink {
     }
     __device__ __forceinline__ void finish() { if (staged) flush(staged); }
 };
+using Sink = SinkT<false>;
 
 }  // namespace sig_mix

@@ -280,16 +280,17 @@ def test_mix_matrix_sink_equals_mix_matrix_over_the_stored_chain(kind):
         if kind == 'Sine':
             # by default a Sine chain reaches the sink through the closed form (fused_steady_mix_kernel): same values to
             # the rounding of the rows, and within 1e-6 (of the mixed rows' scale) of the oracle's chain times the matrix
-            geometry(1, span, steady=1)
-            closed = torch.full((K * N, V), float('nan'), device='cuda')
-            _native.fused_osc_biquad_mix(kind, 'lp', RATE, pos, N, K, CTX, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
-                                         dev(p['gain']), M, closed)
-            closed = closed.cpu().numpy()
-            scale = float(np.abs(want).max())
-            assert np.isfinite(closed).all() and maxerr(closed, want) < 1e-6 * scale, (V, N, K, pos, span)
             ref = oracle_chain(kind, 'lp', p, pos, N, K)
             ref = (ref.reshape(K * N, V // 64, 64) @ M.cpu().numpy().astype(np.float64)).reshape(K * N, V)
-            assert maxerr(closed, f32(ref)) < 2e-6 * scale, (V, N, K, pos, span)
+            scale = float(np.abs(want).max())
+            for steady in (1, 3):                            # 3: the same kernel with its sink on the float32 MFMA (tuning hook)
+                geometry(1, span, steady=steady)
+                closed = torch.full((K * N, V), float('nan'), device='cuda')
+                _native.fused_osc_biquad_mix(kind, 'lp', RATE, pos, N, K, CTX, dev(p['hertz']), dev(p['phase']), dev(p['cutoff']),
+                                             dev(p['gain']), M, closed)
+                closed = closed.cpu().numpy()
+                assert np.isfinite(closed).all() and maxerr(closed, want) < 1e-6 * scale, (V, N, K, pos, span, steady)
+                assert maxerr(closed, f32(ref)) < 2e-6 * scale, (V, N, K, pos, span, steady)
 
 
 def test_tile_sum_inside_the_kernel_equals_the_second_launch_bit_for_bit():
