@@ -241,7 +241,7 @@ def cpu_baseline_sharded(p, voices, frames, workers, blocks=128):
 
 
 # --------------------------------------------------------------------------------------------------- other configs
-def run_config(name: str, steps: int = 0, prewarm_s: float = 0.2) -> dict:
+def run_config(name: str, steps: int = 0, prewarm_s: float = 1.0) -> dict:
     """BASELINE.json's C3 / C5 on this GPU through the engine's default schedule: throughput, per-kernel table, the
     dominant kernel's roofline, and max-abs error of the first rendered batch (the timed launch geometry) against the
     CPU oracle on whole-width blocks."""
@@ -361,9 +361,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--prewarm-ms', type=float, default=250.0,
+    ap.add_argument('--prewarm-ms', type=float, default=1500.0,
                     help='untimed: keep rendering batches for this long before the W warm-up steps, so that the GPU clocks '
-                         'have settled under load (the first ~50 ms after idle run 15-30 % slower); 0 disables')
+                         'have settled under load (the first ~50 ms after idle run 15-30 % slower, and the rate keeps creeping up for ~2 s: '
+                         '4.85 / 5.09 / 5.24 T voice-samples/s after 250 / 1000 / 2000 ms); 0 disables')
     ap.add_argument('--blocks', type=int, default=4096, help='256-frame blocks per batch (one step)')
     ap.add_argument('--voices', type=int, default=1024, help='voices per GPU')
     ap.add_argument('--frames', type=int, default=256)
