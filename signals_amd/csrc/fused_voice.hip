@@ -292,7 +292,7 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
         int done = 0;
         // the exact-phase Sine path is the rare one (positions beyond 2^26 cycles): rolled loops, so that its
         // register needs do not set the kernel's budget
-        constexpr bool GROUPED = FAST || KIND != SIG_OSC_SINE;
+        constexpr bool GROUPED = FAST || KIND != SIG_OSC_SINE || ROWS;           // (ROWS: under block-rate FM the exact phase IS the Sine path)
         if (!OUT || !BUS) {
             constexpr int U = GROUPED ? 4 : 1;                                 // rows per unrolled step
             for (; done + U <= count; done += U) {
@@ -366,7 +366,18 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
             double w0[VPT], w1[VPT];                                           // the next block's chain, from zero state
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { w0[i] = 0.0; w1[i] = 0.0; }
-            if constexpr (ROWS) design_block(b_first + bi + 1, wna1, wna2, [&](int ch, int i, double w) { wwt[ch][i] = w; });
+            if constexpr (ROWS) {
+                if (a.cutoff_rows > 1 || a.gain_rows > 1) {                    // (block-rate FM alone: one design for the launch)
+                    design_block(b_first + bi + 1, wna1, wna2, [&](int ch, int i, double w) { wwt[ch][i] = w; });
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VPT; ++i) {
+                        wna1[i] = na1[i]; wna2[i] = na2[i];
+#pragma unroll
+                        for (int ch = 0; ch < CC; ++ch) wwt[ch][i] = wt[ch][i];
+                    }
+                }
+            }
             walk_any(tail, orow + a.N - tail, w0, w1, std::true_type{}, std::true_type{}, b_first + bi);
 #pragma unroll
             for (int i = 0; i < VPT; ++i) { z0[i] = w0[i]; z1[i] = w1[i]; }
