@@ -227,14 +227,14 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     };
 
     // `count` consecutive rows from n_cur on; OUT rows go to output rows out_row, out_row + 1, ...
-    auto walk = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, auto fast_tag, int64_t blk) {
+    auto walk = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, auto fast_tag, auto pair_tag, int64_t blk) {
         constexpr bool OUT = decltype(out_tag)::value, FAST = decltype(fast_tag)::value;
         double hz[VPT], ph[VPT], q_lane = 0.0;
         int64_t qbase = 0;
         bool q_valid = false;
         if (!FAST) load_hz_ph(hz, ph, blk);
         // second oscillator of a Mix / RingMod source (ROWS kernels only; its waveform is a wave-uniform run-time switch)
-        const bool paired = ROWS && a.pair_op != 0;
+        constexpr bool paired = ROWS && decltype(pair_tag)::value;               // (a compile-time copy of the row code: a run-time test per row cut the groups into pieces)
         double hz2[ROWS ? VPT : 1], ph2[ROWS ? VPT : 1], mx[ROWS ? VPT : 1];
         if constexpr (ROWS) {
             if (paired) {
@@ -353,8 +353,15 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     };
     // `blk`: the block whose hertz / phase rows these rows were made with (only read under block-rate FM)
     auto walk_any = [&](int count, int64_t out_row, double (&w0)[VPT], double (&w1)[VPT], auto out_tag, auto warm_tag, int64_t blk) {
-        if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{}, blk);
-        else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{}, blk);
+        if constexpr (ROWS) {
+            if (a.pair_op != 0) {                                              // wave-uniform
+                if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{}, std::true_type{}, blk);
+                else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{}, std::true_type{}, blk);
+                return;
+            }
+        }
+        if (KIND == SIG_OSC_SINE && fast) walk(count, out_row, w0, w1, out_tag, warm_tag, std::true_type{}, std::false_type{}, blk);
+        else walk(count, out_row, w0, w1, out_tag, warm_tag, std::false_type{}, std::false_type{}, blk);
     };
 
     walk_any(c0, 0, z0, z1, std::false_type{}, std::false_type{}, b_first - 1);   // warm-up of the span's first block: the previous block's samples
