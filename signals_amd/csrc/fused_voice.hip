@@ -85,19 +85,14 @@ __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt,
 // ROWS: cutoff and gain are read per block (the reference reads a control port once per block, at the block's position:
 // chain/__init__.py:305-306 -- an LFO on a cutoff, a tremolo); the filter is then designed per block, the next block's
 // warm-up chain with the next block's design.  GAIN is ignored (a null gain pointer means 1).
-template <int KIND, int VPT, bool GAIN, int C, bool ROWS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
-void fused_walk_kernel(FusedArgs a, BusArgs bus)
+template <int KIND, int VPT, bool GAIN, int C, bool ROWS>
+__device__ __forceinline__ void walk_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
 {
     constexpr bool BUS = C > 0, MIX = C < 0;
     constexpr int CC = BUS ? C : 1;
     constexpr int R = kPairs / CC;         // rows per flush
     static_assert(!MIX || VPT == 1, "the MixMatrix sink maps one matrix group to one wave");
     using Vec = typename OutVec<VPT>::type;
-    __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? sig_mix::kTileRows * sig_mix::kLdsStride / 2 : 1)];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: block / tile indices in SGPRs
-    double* tile = lds[(BUS || MIX) ? wave : 0];
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
     const int vt = (int)(item % a.voice_tiles);
     const int64_t b_first = (item / a.voice_tiles) * a.span;
@@ -400,6 +395,20 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
     }
     if (BUS && stage.staged) stage.now();
     if constexpr (MIX) sink.finish();
+}
+
+template <int KIND, int VPT, bool GAIN, int C, bool ROWS = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Occ<VPT>::lo, Occ<VPT>::hi)))
+void fused_walk_kernel(FusedArgs a, BusArgs bus)
+{
+    constexpr bool BUS = C > 0, MIX = C < 0;
+    __shared__ __attribute__((aligned(16))) double lds[(BUS || MIX) ? 4 : 1][BUS ? kPairs * kTileStride : (MIX ? sig_mix::kTileRows * sig_mix::kLdsStride / 2 : 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform by construction: block / tile indices in SGPRs
+    walk_wave<KIND, VPT, GAIN, C, ROWS>(a, bus, lds[(BUS || MIX) ? wave : 0], lane, wave);
+    if constexpr (BUS) {
+        if (bus.out) sig_bus::sum_tiles_in_workgroup<C>(bus.partials, a.voice_tiles, bus.rows, a.span, a.K, a.N, bus.out, bus.out_ld, lane, wave);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -840,9 +849,10 @@ int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_
     while (max_vpt > 1 && !ok(max_vpt)) max_vpt >>= 1;
     int vpt;
     pick_geometry(a, max_vpt, vpt, a.span);
-    const int err = launch_walk<KIND, false, C, true>(a, bus, vpt, stream);
-    if (err || C == 0) return err;
     const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+    if (C > 0 && sig_bus::tiles_sum_in_workgroup(tiles) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
+    const int err = launch_walk<KIND, false, C, true>(a, bus, vpt, stream);
+    if (err || C == 0 || bus.out) return err;
     return sig_bus::launch_partials<(C > 0 ? C : 1)>(bus.partials, tiles, bus.rows, out, out_ld, stream);
 }
 
@@ -918,8 +928,10 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
         const int e2 = sig_launch_status();
         if (e2 || bus.out) return e2;                                          // (the kernel added the voice tiles itself)
     } else {                                                                   // (Sine with the closed form: that launch did every wave)
+        const int tiles_w = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+        if (sig_bus::tiles_sum_in_workgroup(tiles_w) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
         const int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
-        if (err) return err;
+        if (err || bus.out) return err;                                        // (the kernel added the voice tiles itself)
     }
     const int tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     return sig_bus::launch_partials<C>(bus.partials, tiles, bus.rows, out, out_ld, stream);

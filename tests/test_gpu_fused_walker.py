@@ -304,12 +304,13 @@ def test_tile_sum_inside_the_kernel_equals_the_second_launch_bit_for_bit():
             assert -(-V // (64 * vpt)) == tiles
             for N, K, span, pos, C in ((256, 7, 4, 0, 2), (128, 5, 2, 37, 1), (256, 9, 8, 4096, 2), (64, 3, 1, 100, 1)):
                 p = params(V, 70 + V + N)
-                geometry(vpt, span, steady=2)                # tiles added by partials_kernel
-                two = run_bus('Sine', 'lp', p, pos, N, K, C=C)
-                geometry(vpt, span, steady=1)                # ... by the kernel itself where it can
-                one = run_bus('Sine', 'lp', p, pos, N, K, C=C)
-                assert np.isfinite(one).all() and np.array_equal(one, two), (V, vpt, N, K, span, pos, C)
-        ref = oracle_chain('Sine', 'lp', p, pos, N, K).sum(axis=1, keepdims=True)      # (the last case is mono)
+                for kind in ('Sine', 'Sawtooth'):            # the closed form; the row walker (its voices per lane stop at 4)
+                    geometry(vpt, span, steady=2)            # tiles added by partials_kernel
+                    two = run_bus(kind, 'lp', p, pos, N, K, C=C)
+                    geometry(vpt, span, steady=1)            # ... by the kernel itself where it can
+                    one = run_bus(kind, 'lp', p, pos, N, K, C=C)
+                    assert np.isfinite(one).all() and np.array_equal(one, two), (kind, V, vpt, N, K, span, pos, C)
+        ref = oracle_chain(kind, 'lp', p, pos, N, K).sum(axis=1, keepdims=True)        # (the last case: mono, Sawtooth)
         assert C == 1 and maxerr(one, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max())
     finally:
         geometry(0, 0, steady=-1)
