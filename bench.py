@@ -356,6 +356,43 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 1.0) -> dict:
                               'sample': sample}}
 
 
+def run_modulated(K: int = 1024, steps: int = 30, prewarm_s: float = 0.5) -> dict:
+    """C2's 1024-voice graph with its control ports driven at block rate (vibrato, LFO-swept cutoff, tremolo: what the
+    reference's forward_at_block_rate allows on top of the headline graph; not a BASELINE configuration).  The voice stays one
+    launch -- the row walker with per-block hertz / cutoff / gain rows -- behind a few block-rate control launches."""
+    from oracle import chain_ref as R
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    import warnings
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    V, N = 1024, 256
+    p = cfg.c2_params(V)
+    out = {'workload': f'C2 voices ({V}) with block-rate vibrato + cutoff sweep + tremolo, {N}-frame blocks, {K} blocks per batch',
+           'unit': 'Msamples/s', 'voices': {}}
+    for kind in ('Sawtooth', 'Sine'):
+        timer = KernelTimer(sample_every=4)
+        r = BatchRenderer(cfg.c2_modulated_graph(p, kind), 2, RATE, timer=timer)
+        first = r.render(0, N, K)
+        node, pan = cfg.c2_modulated_oracle(p, kind)
+        ref = R.sum_bus(R.render_stream(node, 0, N, 2, V), pan).astype(np.float32).astype(np.float64)
+        err = float(np.max(np.abs(first[:2 * N].double().cpu().numpy() - ref)))
+        pos = N * K
+        t_end = time.perf_counter() + prewarm_s
+        while time.perf_counter() < t_end:
+            r.render(pos, N, K); pos += N * K
+            torch.cuda.synchronize()
+        timer.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render(pos, N, K); pos += N * K
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        summ = timer.summary()
+        out['voices'][kind] = {'value': V * N * K * steps / dt / 1e6, 'ms_per_step': dt / steps * 1e3,
+                               'max_abs_error_blocks_0_1': err, 'full_scale': float(np.max(np.abs(ref))),
+                               'launches_per_step': {k: round(v['ms'] / v['calls'], 4) for k, v in summ.items()}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -576,6 +613,7 @@ def main():
     configs = None
     if world == 1 and not args.single_mode and not args.no_configs and not args.no_cpu_baseline:
         configs = {name: run_config(name) for name in ('C3', 'C5')}
+        configs['C2_modulated'] = run_modulated()
 
     if rank == 0:
         def describe(fused):

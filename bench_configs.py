@@ -4,6 +4,8 @@ bench.py, tools/measure_configs.py and the full-size tests.  Parameters: numpy d
   C2  1024-voice Fixed -> Sine -> LowPass -> Gain -> SumBus(stereo), N = 256          (the headline)
   C3  1024-voice Sawtooth -> LowPass -> LowPass -> x ADSR -> SumBus(mono), N = 1024
   C5  4096-voice Sine -> LowPass -> MixMatrix(64 x 64), N = 256
+  C2m C2's voice with block-rate modulation (not a BASELINE configuration: what the reference's control ports allow on top of
+      it, chain/__init__.py:305-306): any oscillator, vibrato on hertz, an LFO sweep on the cutoff, a tremolo on the gain
 """
 import numpy as np
 
@@ -113,3 +115,48 @@ def c5_oracle(p: dict):
     from oracle import chain_ref as R
     lp = R.Filter('lp', R.Osc('Sine', R.Fixed(p['hertz']), R.Fixed(p['phase'])), R.Fixed(p['cutoff']))
     return R.MixMatrix(lp, p['matrix'].astype(np.float32).astype(np.float64))     # the GPU multiplies by the float32 matrix
+
+
+# ----------------------------------------------------------------------------------------------- C2 with modulated controls
+def c2_modulated_graph(p: dict, kind: str = 'Sawtooth', vibrato: bool = True, sweep: bool = True, tremolo: bool = True):
+    """C2's voice with its control ports driven at block rate: hertz = p.hertz +- 4.5 Hz at 5.3 Hz, cutoff = p.cutoff x
+    (0.6 + 0.4 sin 1.7 Hz), gain = p.gain x (0.7 + 0.3 sin 3.1 Hz)"""
+    from signals_amd.chain import ext, fx, osc
+
+    def lfo(hz, depth, centre_row):
+        """depth * sin + centre  as  Mix(Gain(Sine, 2 depth), 2 centre, 0.5)"""
+        s_ = osc.Sine(); s_.hertz = fixed([[hz]])
+        g = fx.Gain(); g.left = s_; g.right = fixed([[2.0 * depth]])
+        m = fx.Mix(); m.left = g; m.right = fixed(2.0 * np.asarray(centre_row)); m.mix = fixed([[0.5]])
+        return m
+
+    o = getattr(osc, kind)()
+    o.hertz = lfo(5.3, 4.5, p['hertz']) if vibrato else fixed(p['hertz'])
+    o.phase = fixed(p['phase'])
+    f = fx.LowPass(); f.input = o
+    if sweep:
+        c = fx.RingMod(); c.left = lfo(1.7, 0.4, [[0.6]]); c.right = fixed(p['cutoff'])
+        f.cutoff = c
+    else:
+        f.cutoff = fixed(p['cutoff'])
+    g = fx.Gain(); g.left = f
+    if tremolo:
+        d = fx.RingMod(); d.left = lfo(3.1, 0.3, [[0.7]]); d.right = fixed(p['gain'])
+        g.right = d
+    else:
+        g.right = fixed(p['gain'])
+    bus = ext.SumBus(); bus.input = g
+    bus.get_state().gains = np.ascontiguousarray(p['pan'])
+    return bus
+
+
+def c2_modulated_oracle(p: dict, kind: str = 'Sawtooth', vibrato: bool = True, sweep: bool = True, tremolo: bool = True):
+    from oracle import chain_ref as R
+
+    def lfo(hz, depth, centre_row):
+        return R.Binary('Mix', R.Binary('Gain', R.Osc('Sine', R.Fixed([[hz]])), R.Fixed([[2.0 * depth]])),
+                        R.Fixed(2.0 * np.asarray(centre_row)), R.Fixed([[0.5]]))
+    hertz = lfo(5.3, 4.5, p['hertz']) if vibrato else R.Fixed(p['hertz'])
+    cutoff = R.Binary('RingMod', lfo(1.7, 0.4, [[0.6]]), R.Fixed(p['cutoff'])) if sweep else R.Fixed(p['cutoff'])
+    gain = R.Binary('RingMod', lfo(3.1, 0.3, [[0.7]]), R.Fixed(p['gain'])) if tremolo else R.Fixed(p['gain'])
+    return R.Binary('Gain', R.Filter('lp', R.Osc(kind, hertz, R.Fixed(p['phase'])), cutoff), gain), p['pan']

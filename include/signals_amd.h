@@ -269,6 +269,29 @@ int sig_fused_osc_biquad_devpos(int osc_kind, int filt_type, int32_t rate, const
                                 float* out, int64_t out_ld, int32_t* status, void* stream);
 int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
 
+/* A block-rate control subgraph as one launch.  The reference reads a control port once per block, at the block's position
+ * (BoundPort.forward_at_block_rate, chain/__init__.py:305-306); an LFO sweep or a tremolo is an oscillator evaluated at one
+ * frame per block (Osc._eval, osc.py:26-62) combined by element-wise nodes (fx.py:35-60).  `program` (device memory, n_ins <=
+ * SIG_CTL_MAX_INS) is that subgraph in evaluation order over registers dst < min(n_ins, SIG_CTL_MAX_REGS); thread (b, v) runs it for
+ * block b (frame position + b * step) at column v < cols and writes register outs[k].reg to outs[k].out[b * outs[k].cols + v]
+ * for v < outs[k].cols.  A register index of -1 reads 0.  Same expressions as sig_osc_bank (f64 store) and sig_elementwise,
+ * so the same bits as the node-by-node evaluation. */
+enum { SIG_CTL_ROW = 0, SIG_CTL_OSC = 1, SIG_CTL_GAIN = 2, SIG_CTL_MIX = 3, SIG_CTL_RINGMOD = 4, SIG_CTL_AMP = 5 };
+enum { SIG_CTL_MAX_REGS = 48, SIG_CTL_MAX_INS = 64 };
+typedef struct {
+    int32_t op;              /* SIG_CTL_* */
+    int32_t kind;            /* OSC: SIG_OSC_* */
+    int32_t a, b, c;         /* operand registers.  OSC: a = hertz, b = phase; GAIN / RINGMOD / AMP: a, b; MIX: a, b, c = mix */
+    int32_t dst;             /* result register */
+    int32_t stride, rows;    /* ROW: a (rows, cols) float64 array, rows 1 | nblocks, rows contiguous, element v * stride (cols 1: stride 0) */
+    int32_t cols;            /* EVERY instruction: columns of its result (1: evaluated once per block; the broadcast of its operands' widths otherwise) */
+    int32_t reserved;
+    const double* row;
+} sig_ctl_ins;
+typedef struct { int32_t reg; int32_t cols; double* out; } sig_ctl_out;   /* out: (nblocks, cols) float64, contiguous */
+int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
+                        const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream);
+
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
  * -- Osc._eval (chain/osc.py:26-62), CritFilter._filter (chain/fx.py:85-121), Gain._eval (chain/fx.py:49-52) and the
  * build-defined MixMatrix, i.e. the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going

@@ -32,11 +32,27 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
-           'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm')
+           'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program')
 
 
 class NativeError(RuntimeError):
     """The HIP library is missing, was given a CPU tensor, or returned a hipError_t."""
+
+
+class CtlIns(ctypes.Structure):
+    """sig_ctl_ins: one instruction of a block-rate control program"""
+    _fields_ = [('op', ctypes.c_int32), ('kind', ctypes.c_int32), ('a', ctypes.c_int32), ('b', ctypes.c_int32), ('c', ctypes.c_int32),
+                ('dst', ctypes.c_int32), ('stride', ctypes.c_int32), ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('row', ctypes.c_void_p)]
+
+
+class CtlOut(ctypes.Structure):
+    """sig_ctl_out: a register written to a (nblocks, cols) float64 output"""
+    _fields_ = [('reg', ctypes.c_int32), ('cols', ctypes.c_int32), ('out', ctypes.c_void_p)]
+
+
+CTL_OPS = {'Row': 0, 'Osc': 1, 'Gain': 2, 'Mix': 3, 'RingMod': 4, 'Amp': 5}
+CTL_MAX_REGS, CTL_MAX_INS = 48, 64
 
 
 class Operand(ctypes.Structure):
@@ -140,6 +156,8 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus_fm.restype = ctypes.c_int
         L.sig_fused_voice_bus_fm.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                              dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_control_program.restype = ctypes.c_int
+        L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, vp, i32, vp, i32, vp]
         L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
         L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                 dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
@@ -734,6 +752,26 @@ def fused_cascade_model(voices: int, block_frames: int, nblocks: int, context: i
         + 17.0 * bus_channels / (16 * vpt) + restart * (2 * (span - 1) + 1) / (span * n)
     return {'f64_ops_per_voice_sample': ops, 'voices_per_lane': vpt, 'blocks_per_lane': span,
             'rows_walked_per_output_row': walked}
+
+
+def upload_structs(items: list) -> torch.Tensor:
+    """a list of ctypes structures of one type as a device byte tensor (a control program, its output table)"""
+    arr = (type(items[0]) * len(items))(*items)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(runtime_device())
+
+
+def runtime_device():
+    from . import runtime
+    return runtime.device()
+
+
+def control_program(rate: int, position: int, step: int, nblocks: int, cols: int, program: torch.Tensor, n_ins: int,
+                    outs: torch.Tensor, n_outs: int) -> None:
+    """run a block-rate control program (sig_control_program): `program` / `outs` are device byte tensors of CtlIns / CtlOut"""
+    _gpu(program, outs)
+    _check(lib().sig_control_program(rate, position, step, nblocks, cols, program.data_ptr(), n_ins, outs.data_ptr(), n_outs,
+                                     _stream(program)), 'sig_control_program')
 
 
 def fused_voice_bus_plan(kind: str, position: int, voices: int, block_frames: int, nblocks: int, context: int) -> dict:

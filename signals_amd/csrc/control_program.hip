@@ -1,0 +1,107 @@
+// A whole block-rate control subgraph in ONE launch, gfx950.
+//
+// The reference reads a control port once per block, at the block's position (BoundPort.forward_at_block_rate,
+// chain/__init__.py:305-306): an LFO on a cutoff is an oscillator evaluated at one frame per block, scaled and offset by
+// element-wise nodes (osc.py:26-62, fx.py:35-60).  Node by node that is a handful of launches of a few microseconds of
+// work each -- a vibrato + cutoff sweep + tremolo voice spent half of its batch time (and all of its host time) in eleven
+// of them.  Here the subgraph is a short straight-line program over registers, the same for every (block, column): thread
+// (b, v) evaluates it for block b at column v and writes the requested registers to their (nblocks, cols) outputs.
+// Arithmetic as in the per-node kernels (osc_bank.hip's f64 store path, elementwise.hip's ew_apply): the same expressions
+// under -ffp-contract=off, so the same bits.  Registers live in LDS, [register][thread]: every thread executes the same
+// instruction, so a register index is uniform and the accesses are conflict-free (a private array indexed by a run-time
+// value would go to scratch).  Instruction k writes register dst < n_ins (the host assigns them in instruction order).
+#include "sig_osc.h"
+
+namespace {
+
+constexpr int kMaxRegs = SIG_CTL_MAX_REGS;
+
+constexpr int kThreads = 128;
+
+// One workgroup per block.  The program is copied into LDS once (fetching every instruction from global memory cost a
+// dependent scalar load of ~0.5 us per instruction per wave); the register file behind it is sized by the program (n_regs x
+// 128 threads x 8 B, dynamic LDS).  Instructions whose result is one column wide (an LFO: oscillator, scale, offset) run
+// ONCE per block, before the loop over the columns; only the wide ones (the final products with per-voice rows) run per
+// column chunk -- a vibrato + sweep + tremolo program over 1024 blocks x 1024 voices took 65 us with every (block, column)
+// thread running all 26 instructions, three f64 sines among them.
+__global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, int64_t position, int64_t step, int nblocks, int cols,
+                                                                   const sig_ctl_ins* __restrict__ program, int n_ins,
+                                                                   const sig_ctl_out* __restrict__ outs, int n_outs)
+{
+    __shared__ sig_ctl_ins prog[SIG_CTL_MAX_INS];
+    extern __shared__ double regs[];                                           // [register][thread]
+    {
+        const int words = n_ins * (int)(sizeof(sig_ctl_ins) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(program);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(prog);
+        for (int w = threadIdx.x; w < words; w += kThreads) dst[w] = src[w];
+    }
+    __syncthreads();
+    const int64_t b = blockIdx.x;
+    double* r = regs + threadIdx.x;
+    auto get = [&](int reg) { return reg < 0 ? 0.0 : r[reg * kThreads]; };
+    auto row_value = [&](const sig_ctl_ins& ins, int v) {
+        return ins.row[(ins.rows > 1 ? b * (int64_t)(ins.stride ? ins.cols : 1) : 0) + (int64_t)(v < ins.cols ? v : 0) * ins.stride];
+    };
+    auto execute = [&](const sig_ctl_ins& ins, int v) {
+        double x;
+        switch (ins.op) {
+            case SIG_CTL_ROW: x = row_value(ins, v); break;
+            case SIG_CTL_OSC: {
+                const double t = (double)(position + b * step) / rate * get(ins.a) + get(ins.b);      // osc.py:32
+                switch (ins.kind) {
+                    case SIG_OSC_SINE: x = sig_osc::osc_sine(t); break;
+                    case SIG_OSC_SQUARE: x = sig_osc::osc_square(t); break;
+                    case SIG_OSC_SAWTOOTH: x = sig_osc::osc_sawtooth(t); break;
+                    default: x = sig_osc::osc_triangle(t); break;
+                }
+                break;
+            }
+            case SIG_CTL_MIX: { const double c = get(ins.c); x = c * get(ins.a) + (1.0 - c) * get(ins.b); break; }   // fx.py:40
+            case SIG_CTL_AMP: { const double a = get(ins.a); x = copysign(pow(a, get(ins.b)), a); break; }           // fx.py:60
+            default: x = get(ins.a) * get(ins.b); break;                                                           // Gain, RingMod: fx.py:46, :52
+        }
+        r[ins.dst * kThreads] = x;
+    };
+    // ---- one column wide: once per block (every thread computes the same value into its own copy of the register).
+    // Leading ROW instructions of that kind keep their global loads four in flight.
+    int k0 = 0;
+    while (k0 < n_ins && prog[k0].op == SIG_CTL_ROW && prog[k0].cols == 1) ++k0;
+    for (int k = 0; k < k0; k += 4) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = (k + u < k0) ? row_value(prog[k + u], 0) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k + u < k0) r[prog[k + u].dst * kThreads] = x[u];
+    }
+    for (int k = k0; k < n_ins; ++k)
+        if (prog[k].cols == 1) execute(prog[k], 0);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < n_outs; ++k)
+            if (outs[k].cols == 1) outs[k].out[b] = r[outs[k].reg * kThreads];
+    // ---- wider: per chunk of 128 columns
+    for (int v0 = 0; v0 < cols; v0 += kThreads) {
+        const int v = v0 + threadIdx.x;
+        for (int k = k0; k < n_ins; ++k)
+            if (prog[k].cols > 1) execute(prog[k], v);
+        for (int k = 0; k < n_outs; ++k) {
+            const sig_ctl_out o = outs[k];
+            if (o.cols > 1 && v < o.cols) o.out[b * o.cols + v] = r[o.reg * kThreads];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
+                                   const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream)
+{
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0);
+    SIG_CHECK_ARG((program || n_ins == 0) && (outs || n_outs == 0) && n_ins <= SIG_CTL_MAX_INS);
+    if (nblocks == 0 || n_outs == 0) return 0;
+    int n_regs = 1;                                                            // (the program is in host-visible device memory only: the caller says how many)
+    n_regs = n_ins < SIG_CTL_MAX_REGS ? (n_ins > 0 ? n_ins : 1) : SIG_CTL_MAX_REGS;   // registers are assigned in instruction order (dst < n_ins)
+    control_program_kernel<<<(unsigned)nblocks, kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols,
+                                                                                          program, n_ins, outs, n_outs);
+    return sig_launch_status();
+}

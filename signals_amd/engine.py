@@ -173,6 +173,7 @@ class BatchRenderer:
         self.timer = timer
         self._tails: dict[Emitter, tuple[int, torch.Tensor]] = {}    # node -> (end position, last <=100 rows)
         self._stream_end: int | None = None
+        self._ctl_programs: dict = {}                      # compiled block-rate control programs, by (port sources, K)
         self._prev_block_frames: int | None = None         # N of the previous render (where a fused cascade's history block starts)
         self._virtual_history = False                      # the previous batch kept its filter history implicit (no tails needed)
         self._cascade_stream = False                       # ... and this batch continues it
@@ -301,6 +302,101 @@ def _is_pure(node: Emitter | None, memo: dict) -> bool:
     return memo[node]
 
 
+class _ControlProgram:
+    """The block-rate subgraphs under a set of control ports as ONE launch (sig_control_program): oscillators evaluated at
+    one frame per block, element-wise nodes, Fixed rows -- the same expressions as the node-by-node launches of
+    `_Batch._control_node`, so the same bits.  Compiled once per (ports, K, graph version); Fixed rows are re-checked per run
+    (an edited value re-uploads into a new tensor: recompile).  Outputs are owned by the program and overwritten by the
+    next run -- their consumers are launches enqueued before that on the same stream."""
+
+    def __init__(self, srcs: tuple, K: int):
+        self.srcs, self.K = srcs, K
+        self.ins: list = []
+        self.keep: list[torch.Tensor] = []                  # tensors the instructions point into
+        self.fixed: list[tuple[fixed.Fixed, torch.Tensor]] = []
+        self._reg: dict = {}
+        dev = runtime.device()
+        self._zero = torch.zeros((1, 1), dtype=CTRL_DTYPE, device=dev)
+        self.results: list = []                             # per source: ('row', tensor) | ('out', tensor)
+        outs = []
+        for src in srcs:
+            if src is None or not src.get_state().enabled:
+                self.results.append(Emitter.empty_result())
+            elif isinstance(src, fixed.Fixed):
+                self.results.append(None)                   # its resident row, fetched per run
+            else:
+                reg, cols = self._emit(src)
+                out = torch.empty((K, cols), dtype=CTRL_DTYPE, device=dev)
+                outs.append(_native.CtlOut(reg, cols, out.data_ptr()))
+                self.results.append(out)
+        self.cols = max([c for _, c in self._reg.values()] + [1])
+        # Row instructions first (they depend on nothing; the kernel keeps the one-column ones' loads four in flight), registers renumbered
+        row_op = _native.CTL_OPS['Row']
+        rank = lambda x: 2 if x.op != row_op else (0 if x.cols == 1 else 1)      # one-column rows, wide rows, the rest
+        order = sorted(range(len(self.ins)), key=lambda i: (rank(self.ins[i]), i))
+        new_of = {old: new for new, old in enumerate(order)}
+        self.ins = [self.ins[i] for i in order]
+        for x in self.ins:
+            x.dst = new_of[x.dst]
+            x.a, x.b, x.c = (new_of.get(r, -1) for r in (x.a, x.b, x.c))
+        for o in outs:
+            o.reg = new_of[o.reg]
+        self.n_ins, self.n_outs = len(self.ins), len(outs)
+        self.program_t = _native.upload_structs(self.ins) if self.ins else None
+        self.outs_t = _native.upload_structs(outs) if outs else None
+
+    def _row(self, t: torch.Tensor) -> tuple[int, int]:
+        if t.shape[0] != 1:
+            raise NotBatchable('multi-row Fixed on a control port')
+        t = as_control(t)
+        self.keep.append(t)
+        cols = t.shape[1]
+        return self._push(_native.CtlIns(_native.CTL_OPS['Row'], 0, -1, -1, -1, 0, 0 if cols == 1 else 1, 1, cols, 0, t.data_ptr()), cols)
+
+    def _push(self, ins, cols: int) -> tuple[int, int]:
+        reg = len(self.ins)
+        if reg >= _native.CTL_MAX_REGS:
+            raise NotBatchable('control subgraph larger than one program')
+        ins.dst = reg
+        self.ins.append(ins)
+        return reg, cols
+
+    def _emit(self, src) -> tuple[int, int]:
+        if src is None or not src.get_state().enabled:
+            key = None
+            if key not in self._reg:
+                self._reg[key] = self._row(self._zero)
+            return self._reg[key]
+        if src in self._reg:
+            return self._reg[src]
+        if isinstance(src, fixed.Fixed):
+            row = src.resident()
+            self.fixed.append((src, row))
+            got = self._row(row)
+        elif isinstance(src, osc.Osc):
+            (a, ca), (b, cb) = self._emit(src.hertz.sig), self._emit(src.phase.sig)
+            got = self._push(_native.CtlIns(_native.CTL_OPS['Osc'], _native.OSC_KINDS[src.kind()], a, b, -1, 0, 0, 0, max(ca, cb), 0, None), max(ca, cb))
+        elif isinstance(src, (fx.Gain, fx.Amp, fx.Mix, fx.RingMod)):
+            (a, ca), (b, cb) = self._emit(src.left.sig), self._emit(src.right.sig)
+            c, cc = self._emit(src.mix.sig) if isinstance(src, fx.Mix) else (-1, 1)
+            cols = broadcast_shape((1, ca), (1, cb), (1, cc))[1]
+            got = self._push(_native.CtlIns(_native.CTL_OPS[type(src).__name__], 0, a, b, c, 0, 0, 0, cols, 0, None), cols)
+        else:
+            raise NotBatchable(f'no block-rate program for {src.cls_name()}')
+        self._reg[src] = got
+        return got
+
+    def current(self) -> bool:
+        return all(f.resident() is t for f, t in self.fixed)
+
+    def run(self, owner, rate: int, position: int, step: int) -> list[torch.Tensor]:
+        if self.n_outs:
+            owner._launch('control_program[block-rate]',
+                          lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
+                                                          self.outs_t, self.n_outs), units=self.K * self.cols)
+        return [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
+
+
 class _Batch:
     """One render call: position, N, K fixed; buffers memoised per (node, channels)."""
 
@@ -332,6 +428,22 @@ class _Batch:
         """(1, C) if the value holds for every block, else (K, C): row b is the port's reply to the block-rate
         request at position pos + b*N (forward_at_block_rate of block b)."""
         return self._control_node(port.sig, what)
+
+    def _control_many(self, ports: list) -> list[torch.Tensor]:
+        """the block-rate replies of several control ports, their subgraphs evaluated in one launch where they consist of
+        oscillators, element-wise nodes and Fixed rows (else node by node, like `_control`)"""
+        o = self.owner
+        srcs = tuple(p.sig for p in ports)
+        key = (tuple(id(x) for x in srcs), self.K)
+        try:
+            held = o._ctl_programs.get(key)
+            if held is None or held[0] != graph_clock.version or not held[1].current():
+                if len(o._ctl_programs) > 16:
+                    o._ctl_programs.clear()
+                held = o._ctl_programs[key] = (graph_clock.version, _ControlProgram(srcs, self.K))
+            return held[1].run(o, self.rate, self.pos, self.N)
+        except NotBatchable:
+            return [self._control(p, p.name) for p in ports]
 
     def _control_node(self, src: Emitter | None, what: str) -> torch.Tensor:
         if src is None or not src.get_state().enabled:
@@ -903,30 +1015,32 @@ class _VoiceChain:
         if not all(n.get_state().enabled for n in self.involved):
             return None
         try:
-            if self.fm:
-                # hertz / phase driven by a block-rate signal: K rows each, and the row of the block in FRONT of the batch --
-                # the reference's oscillators keep their previous block (BlockCachingEmitter), so block 0's context rows are
-                # that block's samples: the previous batch's last block on a contiguous stream, else the context request
-                # [pos - c, pos) answered as a block of its own (its controls read at pos - c)
-                b, o = self.batch, self.batch.owner
-                rows = [as_control(b._control(p, p.name)) for p in self.ports[:2]]
-                contiguous = o._stream_end == b.pos and bool(o._prev_block_frames) and o._prev_block_frames >= min(CONTEXT, b.pos)
-                q = b.pos - (o._prev_block_frames if contiguous else min(CONTEXT, b.pos))
-                front = _Batch(o, q, max(b.pos - q, 2), 1, False)
-                self.hist_rows = tuple(None if _ctl_const(p) else as_control(front._control(p, p.name)) for p in self.ports[:2])
-            else:
-                rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]
             if self.pair is not None:
                 op, second = self.pair
                 self.pair_rows = (self.batch._control_const(second.hertz, 'hertz'), self.batch._control_const(second.phase, 'phase'),
                                   self.batch._control_const(op.mix, 'mix') if isinstance(op, fx.Mix) else None)
             if self.modulated:
-                # cutoff / gain driven by a computed block-rate signal (an LFO sweep, a tremolo): K rows, one per block
-                rows.append(as_control(self.batch._control(self.filt.cutoff, 'cutoff')))
-                gains = [as_control(self.batch._control(p, p.name)) for p in self.gain_ports]
+                # hertz / phase / cutoff / gain driven by computed block-rate signals (vibrato, an LFO sweep, a tremolo): K rows
+                # each, one per block, all of them from ONE control-program launch
+                b, o = self.batch, self.batch.owner
+                ports = self.ports[:2] + [self.filt.cutoff] + self.gain_ports
+                vals = [as_control(t) for t in b._control_many(ports)]
+                rows, gains = vals[:3], vals[3:]
+                if self.fm:
+                    # ... and the hertz / phase of the block in FRONT of the batch: the reference's oscillators keep their
+                    # previous block (BlockCachingEmitter), so block 0's context rows are that block's samples -- the previous
+                    # batch's last block on a contiguous stream, else the context request [pos - c, pos) answered as a block
+                    # of its own (its controls read at pos - c)
+                    contiguous = o._stream_end == b.pos and bool(o._prev_block_frames) and o._prev_block_frames >= min(CONTEXT, b.pos)
+                    q = b.pos - (o._prev_block_frames if contiguous else min(CONTEXT, b.pos))
+                    front = _Batch(o, q, max(b.pos - q, 2), 1, False)
+                    mod = [p for p in self.ports[:2] if not _ctl_const(p)]
+                    got = iter(front._control_many(mod))
+                    self.hist_rows = tuple(None if _ctl_const(p) else as_control(next(got)) for p in self.ports[:2])
                 if len(gains) == 2:
                     gains = [(gains[0] * gains[1]).contiguous()]
                 return rows + (gains or [None])
+            rows = [self.batch._control_const(p, p.name) for p in self.ports[:2]]
             rows.append(self.batch._control_const(self.filt.cutoff, 'cutoff'))
             gains = [self.batch._control_const(p, p.name) for p in self.gain_ports]
         except NotBatchable:

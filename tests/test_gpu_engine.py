@@ -812,6 +812,51 @@ def test_lfo_swept_cutoff_and_tremolo_run_in_the_fused_chain(golden):
                 assert maxerr(got, eager) < 1e-6, (kind, bus, tremolo)
 
 
+def test_control_program_equals_the_node_by_node_evaluation_bit_for_bit():
+    """sig_control_program: a block-rate control subgraph (oscillators of every waveform, Gain / Mix / RingMod / Amp, Fixed rows
+    one column or V wide, shared sub-expressions, an unplugged port, a disabled node) compiled into one launch gives the
+    bits of the node-by-node block-rate launches (the same expressions under -ffp-contract=off), for several ports at
+    once, K = 1 and K = 37, mid-stream positions"""
+    from signals_amd.chain import Receiver, fx, port
+    from signals_amd.engine import BatchRenderer, _Batch
+    rng = np.random.default_rng(5)
+    V = 70
+    wide, wide2 = rng.uniform(0.2, 2.0, (1, V)), rng.uniform(-1.0, 1.0, (1, V))
+    lfo = mkosc('Sine', [[1.3]])
+    tri = mkosc('Triangle', rng.uniform(0.5, 9.0, (1, V)), rng.uniform(0, 1, (1, V)))           # a V-wide LFO bank
+    sq = mkosc('Square', [[0.7]], [[0.1]])
+    saw = mkosc('Sawtooth', [[2.9]])
+    scaled = fx.Gain(); scaled.left = lfo; scaled.right = fix([[0.4]])
+    offset = fx.Mix(); offset.left = scaled; offset.right = fix(wide); offset.mix = fix([[0.25]])
+    prod = fx.RingMod(); prod.left = offset; prod.right = tri
+    amp = fx.Amp(); amp.left = prod; amp.right = fix([[1.5]])
+    shared = fx.Mix(); shared.left = scaled; shared.right = sq; shared.mix = fix(np.abs(wide2))   # `scaled` used twice
+    off = fx.Gain(); off.left = saw; off.right = fix(wide2); off.get_state().enabled = False      # a disabled node answers zeros
+    hole = fx.RingMod(); hole.left = saw                                                           # right unplugged
+
+    class Ports(Receiver):
+        a = port('a'); b = port('b'); c = port('c'); d = port('d'); e = port('e'); f = port('f')
+        HOST_ARRAYS = False
+
+        @classmethod
+        def flags(cls):
+            from signals_amd import SignalFlags
+            return SignalFlags(0)
+    host = Ports()
+    host.a, host.b, host.c, host.d, host.e, host.f = amp, shared, off, hole, fix(wide), lfo
+    ports = [host.a, host.b, host.c, host.d, host.e, host.f]
+    r = BatchRenderer(lfo, 1, RATE)
+    for pos, N, K in ((0, 256, 37), (48000 * 3 + 17, 128, 1), (999, 64, 5)):
+        one = _Batch(r, pos, N, K, False)._control_many(ports)
+        ref = [_Batch(r, pos, N, K, False)._control(p, p.name) for p in ports]
+        torch.cuda.synchronize()
+        for name, x, y in zip('abcdef', one, ref):
+            assert x.shape[1] == y.shape[1] and np.array_equal(np.broadcast_to(x.cpu().numpy(), np.broadcast_shapes(x.shape, y.shape)),
+                                                               np.broadcast_to(y.cpu().numpy(), np.broadcast_shapes(x.shape, y.shape)),
+                                                               equal_nan=True), (name, pos, N, K)        # (Amp of a negative base: NaN either way)
+    assert len(r._ctl_programs) == 3 and all(prog.n_outs == 4 for _, prog in r._ctl_programs.values())   # a, b, d, f computed; c is a disabled node, e a Fixed row
+
+
 def test_block_rate_fm_runs_in_the_fused_chain(golden):
     """hertz (vibrato) and phase driven by block-rate signals (Osc reads both ports once per block, osc.py:28-30): the voice
     chain stays ONE launch with per-block hertz / phase rows (sig_fused_osc_biquad_fm / sig_fused_voice_bus_fm).  The
