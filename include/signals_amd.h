@@ -288,8 +288,10 @@ typedef struct {
     int32_t reserved;
     const double* row;
 } sig_ctl_ins;
-typedef struct { int32_t reg; int32_t cols; double* out; } sig_ctl_out;   /* out: (nblocks, cols) float64, contiguous */
-int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
+typedef struct { int32_t reg; int32_t cols; double* out; double* front; } sig_ctl_out;   /* out: (nblocks, cols) float64, contiguous; front: (1, cols) or NULL */
+/* front_position >= 0: the program is evaluated once more, at that frame position, into the outputs' `front` rows (the
+ * controls of the block in front of the batch -- sig_fused_*_fm's *_hist -- without a launch of their own); -1: not. */
+int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols, int64_t front_position,
                         const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream);
 
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix

@@ -48,7 +48,7 @@ class CtlIns(ctypes.Structure):
 
 class CtlOut(ctypes.Structure):
     """sig_ctl_out: a register written to a (nblocks, cols) float64 output"""
-    _fields_ = [('reg', ctypes.c_int32), ('cols', ctypes.c_int32), ('out', ctypes.c_void_p)]
+    _fields_ = [('reg', ctypes.c_int32), ('cols', ctypes.c_int32), ('out', ctypes.c_void_p), ('front', ctypes.c_void_p)]
 
 
 CTL_OPS = {'Row': 0, 'Osc': 1, 'Gain': 2, 'Mix': 3, 'RingMod': 4, 'Amp': 5}
@@ -157,7 +157,7 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus_fm.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                              dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_control_program.restype = ctypes.c_int
-        L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, vp, i32, vp, i32, vp]
+        L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, i64, vp, i32, vp, i32, vp]
         L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
         L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                 dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
@@ -767,11 +767,12 @@ def runtime_device():
 
 
 def control_program(rate: int, position: int, step: int, nblocks: int, cols: int, program: torch.Tensor, n_ins: int,
-                    outs: torch.Tensor, n_outs: int) -> None:
-    """run a block-rate control program (sig_control_program): `program` / `outs` are device byte tensors of CtlIns / CtlOut"""
+                    outs: torch.Tensor, n_outs: int, front_position: int = -1) -> None:
+    """run a block-rate control program (sig_control_program): `program` / `outs` are device byte tensors of CtlIns / CtlOut;
+    `front_position` >= 0 also evaluates it at that position into the outputs' `front` rows"""
     _gpu(program, outs)
-    _check(lib().sig_control_program(rate, position, step, nblocks, cols, program.data_ptr(), n_ins, outs.data_ptr(), n_outs,
-                                     _stream(program)), 'sig_control_program')
+    _check(lib().sig_control_program(rate, position, step, nblocks, cols, front_position, program.data_ptr(), n_ins,
+                                     outs.data_ptr(), n_outs, _stream(program)), 'sig_control_program')
 
 
 def fused_voice_bus_plan(kind: str, position: int, voices: int, block_frames: int, nblocks: int, context: int) -> dict:

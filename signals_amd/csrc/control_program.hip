@@ -25,6 +25,7 @@ constexpr int kThreads = 128;
 // column chunk -- a vibrato + sweep + tremolo program over 1024 blocks x 1024 voices took 65 us with every (block, column)
 // thread running all 26 instructions, three f64 sines among them.
 __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, int64_t position, int64_t step, int nblocks, int cols,
+                                                                   int64_t front_position,
                                                                    const sig_ctl_ins* __restrict__ program, int n_ins,
                                                                    const sig_ctl_out* __restrict__ outs, int n_outs)
 {
@@ -37,7 +38,11 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
         for (int w = threadIdx.x; w < words; w += kThreads) dst[w] = src[w];
     }
     __syncthreads();
-    const int64_t b = blockIdx.x;
+    // the last workgroup of a launch with a front position evaluates the program ONCE more, at that position, into the
+    // outputs' `front` rows (the controls of the block in front of the batch: sig_fused_*_fm's *_hist)
+    const bool front = front_position >= 0 && blockIdx.x == (unsigned)nblocks;
+    const int64_t b = front ? 0 : blockIdx.x;
+    if (front) { position = front_position; step = 0; }
     double* r = regs + threadIdx.x;
     auto get = [&](int reg) { return reg < 0 ? 0.0 : r[reg * kThreads]; };
     auto row_value = [&](const sig_ctl_ins& ins, int v) {
@@ -78,7 +83,10 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
         if (prog[k].cols == 1) execute(prog[k], 0);
     if (threadIdx.x == 0)
         for (int k = 0; k < n_outs; ++k)
-            if (outs[k].cols == 1) outs[k].out[b] = r[outs[k].reg * kThreads];
+            if (outs[k].cols == 1) {
+                if (!front) outs[k].out[b] = r[outs[k].reg * kThreads];
+                else if (outs[k].front) outs[k].front[0] = r[outs[k].reg * kThreads];
+            }
     // ---- wider: per chunk of 128 columns
     for (int v0 = 0; v0 < cols; v0 += kThreads) {
         const int v = v0 + threadIdx.x;
@@ -86,7 +94,10 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
             if (prog[k].cols > 1) execute(prog[k], v);
         for (int k = 0; k < n_outs; ++k) {
             const sig_ctl_out o = outs[k];
-            if (o.cols > 1 && v < o.cols) o.out[b * o.cols + v] = r[o.reg * kThreads];
+            if (o.cols > 1 && v < o.cols) {
+                if (!front) o.out[b * o.cols + v] = r[o.reg * kThreads];
+                else if (o.front) o.front[v] = r[o.reg * kThreads];
+            }
         }
     }
 }
@@ -94,14 +105,15 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
 }  // namespace
 
 extern "C" int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
+                                   int64_t front_position,
                                    const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream)
 {
-    SIG_CHECK_ARG(rate > 0 && position >= 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0);
+    SIG_CHECK_ARG(rate > 0 && position >= 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0 && front_position >= -1);
     SIG_CHECK_ARG((program || n_ins == 0) && (outs || n_outs == 0) && n_ins <= SIG_CTL_MAX_INS);
-    if (nblocks == 0 || n_outs == 0) return 0;
+    if ((nblocks == 0 && front_position < 0) || n_outs == 0) return 0;
     int n_regs = 1;                                                            // (the program is in host-visible device memory only: the caller says how many)
     n_regs = n_ins < SIG_CTL_MAX_REGS ? (n_ins > 0 ? n_ins : 1) : SIG_CTL_MAX_REGS;   // registers are assigned in instruction order (dst < n_ins)
-    control_program_kernel<<<(unsigned)nblocks, kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols,
+    control_program_kernel<<<(unsigned)(nblocks + (front_position >= 0 ? 1 : 0)), kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols, front_position,
                                                                                           program, n_ins, outs, n_outs);
     return sig_launch_status();
 }

@@ -317,7 +317,8 @@ class _ControlProgram:
         self._reg: dict = {}
         dev = runtime.device()
         self._zero = torch.zeros((1, 1), dtype=CTRL_DTYPE, device=dev)
-        self.results: list = []                             # per source: ('row', tensor) | ('out', tensor)
+        self.results: list = []                             # per source: a constant row, None (a Fixed: its resident row, per run) or the output
+        self.fronts: dict[int, torch.Tensor] = {}           # per computed source: its (1, cols) row at the front position
         outs = []
         for src in srcs:
             if src is None or not src.get_state().enabled:
@@ -327,8 +328,10 @@ class _ControlProgram:
             else:
                 reg, cols = self._emit(src)
                 out = torch.empty((K, cols), dtype=CTRL_DTYPE, device=dev)
-                outs.append(_native.CtlOut(reg, cols, out.data_ptr()))
+                front = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
+                outs.append(_native.CtlOut(reg, cols, out.data_ptr(), front.data_ptr()))
                 self.results.append(out)
+                self.fronts[len(self.results) - 1] = front
         self.cols = max([c for _, c in self._reg.values()] + [1])
         # Row instructions first (they depend on nothing; the kernel keeps the one-column ones' loads four in flight), registers renumbered
         row_op = _native.CTL_OPS['Row']
@@ -389,12 +392,16 @@ class _ControlProgram:
     def current(self) -> bool:
         return all(f.resident() is t for f, t in self.fixed)
 
-    def run(self, owner, rate: int, position: int, step: int) -> list[torch.Tensor]:
+    def run(self, owner, rate: int, position: int, step: int, front_position: int = -1):
+        """the K-row replies; with `front_position` also the (1, cols) replies at that position -> (rows, fronts)"""
         if self.n_outs:
             owner._launch('control_program[block-rate]',
                           lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
-                                                          self.outs_t, self.n_outs), units=self.K * self.cols)
-        return [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
+                                                          self.outs_t, self.n_outs, front_position), units=self.K * self.cols)
+        rows = [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
+        if front_position < 0:
+            return rows
+        return rows, [self.fronts.get(i, rows[i]) for i in range(len(rows))]
 
 
 class _Batch:
@@ -429,9 +436,10 @@ class _Batch:
         request at position pos + b*N (forward_at_block_rate of block b)."""
         return self._control_node(port.sig, what)
 
-    def _control_many(self, ports: list) -> list[torch.Tensor]:
+    def _control_many(self, ports: list, front_position: int = -1):
         """the block-rate replies of several control ports, their subgraphs evaluated in one launch where they consist of
-        oscillators, element-wise nodes and Fixed rows (else node by node, like `_control`)"""
+        oscillators, element-wise nodes and Fixed rows (else node by node, like `_control`); with `front_position` also their
+        one-row replies at that position: (rows, fronts)"""
         o = self.owner
         srcs = tuple(p.sig for p in ports)
         key = (tuple(id(x) for x in srcs), self.K)
@@ -441,9 +449,13 @@ class _Batch:
                 if len(o._ctl_programs) > 16:
                     o._ctl_programs.clear()
                 held = o._ctl_programs[key] = (graph_clock.version, _ControlProgram(srcs, self.K))
-            return held[1].run(o, self.rate, self.pos, self.N)
+            return held[1].run(o, self.rate, self.pos, self.N, front_position)
         except NotBatchable:
-            return [self._control(p, p.name) for p in ports]
+            rows = [self._control(p, p.name) for p in ports]
+            if front_position < 0:
+                return rows
+            front = _Batch(o, front_position, 2, 1, False)
+            return rows, [front._control(p, p.name) for p in ports]
 
     def _control_node(self, src: Emitter | None, what: str) -> torch.Tensor:
         if src is None or not src.get_state().enabled:
@@ -1024,19 +1036,20 @@ class _VoiceChain:
                 # each, one per block, all of them from ONE control-program launch
                 b, o = self.batch, self.batch.owner
                 ports = self.ports[:2] + [self.filt.cutoff] + self.gain_ports
-                vals = [as_control(t) for t in b._control_many(ports)]
-                rows, gains = vals[:3], vals[3:]
+                # ... and, under block-rate FM, the hertz / phase of the block in FRONT of the batch (evaluated by the same
+                # launch): the reference's oscillators keep their previous block (BlockCachingEmitter), so block 0's context rows
+                # are that block's samples -- the previous batch's last block on a contiguous stream, else the context request
+                # [pos - c, pos) answered as a block of its own (its controls read at pos - c)
+                q = -1
                 if self.fm:
-                    # ... and the hertz / phase of the block in FRONT of the batch: the reference's oscillators keep their
-                    # previous block (BlockCachingEmitter), so block 0's context rows are that block's samples -- the previous
-                    # batch's last block on a contiguous stream, else the context request [pos - c, pos) answered as a block
-                    # of its own (its controls read at pos - c)
                     contiguous = o._stream_end == b.pos and bool(o._prev_block_frames) and o._prev_block_frames >= min(CONTEXT, b.pos)
                     q = b.pos - (o._prev_block_frames if contiguous else min(CONTEXT, b.pos))
-                    front = _Batch(o, q, max(b.pos - q, 2), 1, False)
-                    mod = [p for p in self.ports[:2] if not _ctl_const(p)]
-                    got = iter(front._control_many(mod))
-                    self.hist_rows = tuple(None if _ctl_const(p) else as_control(next(got)) for p in self.ports[:2])
+                got = b._control_many(ports, q)
+                vals, fronts = (got, None) if q < 0 else got
+                vals = [as_control(t) for t in vals]
+                rows, gains = vals[:3], vals[3:]
+                if self.fm:
+                    self.hist_rows = tuple(None if _ctl_const(p) else as_control(f) for p, f in zip(self.ports[:2], fronts[:2]))
                 if len(gains) == 2:
                     gains = [(gains[0] * gains[1]).contiguous()]
                 return rows + (gains or [None])
