@@ -219,7 +219,8 @@ int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t 
  * warm-up chain already runs on the samples at hand.  For the launch's first block that row is *_hist (one (1,V)|(1,1)
  * row, same stride; non-NULL marks the parameter as modulated -- also in a one-block launch, whose single row still has a
  * different row in front; required when the matching *_rows > 1): the previous batch's last row on a continuing stream, the
- * controls evaluated at position - min(context, position) on a fresh graph.  Sine then takes the exact per-row phase. */
+ * controls evaluated at position - min(context, position) on a fresh graph.  Sine's incremental phase is re-seeded at every
+ * block's first row with that block's hertz / phase. */
 int sig_fused_osc_biquad_fm(int osc_kind, int filt_type, int32_t rate, int64_t position,
                             int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                             const double* hertz, int32_t hertz_stride, int32_t hertz_rows, const double* hertz_hist,

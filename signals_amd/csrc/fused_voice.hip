@@ -147,14 +147,18 @@ __device__ __forceinline__ void walk_wave(const FusedArgs& a, const BusArgs& bus
         }
     };
 
-    // Sine as a two-term recurrence (see the header): seeded at the span's first row
+    // Sine as a two-term recurrence (see the header): seeded at the span's first row; under block-rate FM at every block's
+    // first row (and for the span's warm-up rows) with that block's hertz / phase -- the recurrence then never runs longer
+    // than a block
     bool fast = false;
     double sx[VPT], sdl[VPT], snm[VPT];                                        // x, d, -m
-    if (KIND == SIG_OSC_SINE) {
+    int64_t seeded_blk = b_first - 1;                                          // FM: the block whose rows the recurrence was last seeded for
+    // seeds for rows from frame n on, made with parameter row `blk`; returns whether every voice qualifies up to frame n_last
+    auto seed_sine = [&](int64_t blk, int64_t n, int64_t n_last) {
         double hz[VPT], ph[VPT];
-        load_hz_ph(hz, ph);
-        const double q_first = (double)(p0 - c0) / a.rate;                     // osc.py:32
-        const double q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
+        load_hz_ph(hz, ph, blk);
+        const double q_first = (double)n / a.rate;                             // osc.py:32
+        const double q_last = (double)n_last / a.rate;
         bool small = true;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
@@ -169,7 +173,18 @@ __device__ __forceinline__ void walk_wave(const FusedArgs& a, const BusArgs& bus
             sdl[i] = 2.0 * sh * sin2pi(f0 + 0.5 * dr + 0.25);                  // x_1 - x_0
             snm[i] = -4.0 * sh * sh;
         }
-        fast = __all(small) && !fm;                                            // (the incremental phase assumes one hertz for the span)
+        return small;
+    };
+    if (KIND == SIG_OSC_SINE) {
+        bool small = true;
+        if (fm) {                                                              // every block of the span must qualify with its own row
+            for (int bi = nb - 1; bi >= 0; --bi)
+                small &= seed_sine(b_first + bi, p0 + (int64_t)bi * a.N, p0 + (int64_t)(bi + 1) * a.N - 1);
+            small &= seed_sine(b_first - 1, p0 - c0, p0 - 1 >= p0 - c0 ? p0 - 1 : p0 - c0);     // (last: the warm-up rows come first)
+        } else {
+            small = seed_sine(0, p0 - c0, p0 + (int64_t)nb * a.N - 1);
+        }
+        fast = __all(small);
     }
 
     float* dst = (BUS || MIX) ? nullptr : a.out + vc;                          // row index = frame - position
@@ -228,6 +243,12 @@ __device__ __forceinline__ void walk_wave(const FusedArgs& a, const BusArgs& bus
         int64_t qbase = 0;
         bool q_valid = false;
         if (!FAST) load_hz_ph(hz, ph, blk);
+        if constexpr (FAST && ROWS) {
+            if (fm && blk != seeded_blk) {                                     // wave-uniform: a new block's hertz / phase
+                seed_sine(blk, n_cur, n_cur);
+                seeded_blk = blk;
+            }
+        }
         // second oscillator of a Mix / RingMod source (ROWS kernels only; its waveform is a wave-uniform run-time switch)
         constexpr bool paired = ROWS && decltype(pair_tag)::value;               // (a compile-time copy of the row code: a run-time test per row cut the groups into pieces)
         double hz2[ROWS ? VPT : 1], ph2[ROWS ? VPT : 1], mx[ROWS ? VPT : 1];
