@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Non-headline configurations of BASELINE.json (C3, C5) on one MI355X: Msamples/s and per-kernel algorithmic
+"""Non-headline configurations of BASELINE.json (C3, C5) and a modulated C2 voice on one MI355X: Msamples/s and per-kernel algorithmic
 GB/s through the batched engine.  Parity for these graphs is in tests/test_gpu_engine.py; this only times them.
 
     python tools/measure_configs.py            (needs a GPU)
@@ -23,6 +23,11 @@ import bench_configs as cfg
 def c3(V):
     """Saw -> LowPass -> LowPass -> (x ADSR) -> SumBus, N = 1024"""
     return cfg.c3_graph(cfg.c3_params(V)), 1, 1024, 1024, ALGO
+
+
+def c2m(V, K=1024):
+    """C2's voices with block-rate vibrato + cutoff sweep + tremolo (Sawtooth), N = 256"""
+    return cfg.c2_modulated_graph(cfg.c2_params(V), 'Sawtooth'), 2, 256, K, ALGO
 
 
 def c5(V, K=256):
@@ -65,3 +70,4 @@ if __name__ == '__main__':
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     run('C3 saw->LP->LP->xADSR->bus', c3, 1024, steps)
     run('C5 sine->LP->MixMatrix', c5, 4096, steps)
+    run('C2 voices with vibrato + cutoff sweep + tremolo', c2m, 1024, steps)
