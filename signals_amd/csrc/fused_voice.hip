@@ -524,7 +524,8 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
                 const double y = x + z0[i];
                 z0[i] = fma(na1, y, fma(s2, x, z1[i]));
                 z1[i] = fma(na2, y, x);
-                const double scale = live ? sc[(int64_t)SC_SCALE * a.voices + v] : 0.0;
+                double scale = live ? sc[(int64_t)SC_SCALE * a.voices + v] : 0.0;
+                if (a.gain_rows > 1) scale *= a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];   // per-block gain rows (the constants then hold b0 only)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) acc[ch] = fma(bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale, y, acc[ch]);
             }
@@ -564,7 +565,9 @@ template <int VPT> struct SteadyVariants {
 #endif
 template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ? SIG_STEADY_OCC16 : (VPT == 8) ? SIG_STEADY_OCC8 : 2; };
 
-template <int VPT, int C>
+// GROWS: the gain is read per block (a tremolo: sig_fused_voice_bus_rows with rows for the gain only); the constants then hold
+// b0 alone and the bus weights are rebuilt at every block's first row
+template <int VPT, int C, bool GROWS>
 __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
 {
     constexpr int R = kPairs / C;          // rows per flush
@@ -731,6 +734,16 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
     using Variants = SteadyVariants<VPT>;
 
     for (int bi = 0; bi < nb; ++bi) {
+        if constexpr (GROWS) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const bool live = v0 + i < a.voices;
+                const int v = live ? v0 + i : vc;
+                const double scale = sc[(int64_t)SC_SCALE * a.voices + v] * a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0;
+            }
+        }
         // homogeneous state at the block's first row; only the launch's very first block can have a short context
         const bool first = (b_first + bi == 0);
         const int tk = first ? SC_T0 : SC_T;
@@ -789,14 +802,14 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
     if (stage.staged) stage.now();
 }
 
-template <int VPT, int C>
+template <int VPT, int C, bool GROWS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
 void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     __shared__ double lds[4][kPairs * kTileStride];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
-    steady_bus_wave<VPT, C>(a, bus, lds[wave], lane, wave);                    // everything derived from it lives in SGPRs and branches are scalar
+    steady_bus_wave<VPT, C, GROWS>(a, bus, lds[wave], lane, wave);             // everything derived from it lives in SGPRs and branches are scalar
     if (bus.out) sig_bus::sum_tiles_in_workgroup<C>(bus.partials, a.voice_tiles, bus.rows, a.span, a.K, a.N, bus.out, bus.out_ld, lane, wave);
 }
 
@@ -859,10 +872,30 @@ int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
     return sig_launch_status();
 }
 
-// the per-block-parameter entry points (sig_fused_osc_biquad_rows, sig_fused_voice_bus_rows): always the walker
+struct BusPlan { int vpt, span, steady; };
+BusPlan plan_voice_bus(const FusedArgs& a, int kind);
+template <bool GAIN, int C, bool GROWS>
+int launch_steady(FusedArgs& a, BusArgs& bus, int vpt, float* out, int64_t out_ld, hipStream_t stream);
+
+// the per-block-parameter entry points (sig_fused_osc_biquad_rows, sig_fused_voice_bus_rows, *_fm, *_pair): the walker --
+// except a Sine voice whose ONLY per-block parameter is its gain (a tremolo), which keeps the closed form with the bus
+// weights rebuilt at every block's first row (fused_steady_bus_kernel<.., GROWS = true>)
 template <int KIND, int C>
 int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
+    if constexpr (KIND == SIG_OSC_SINE && C > 0) {
+        if (a.gain && a.gain_rows > 1 && a.cutoff_rows == 1 && !a.hertz_hist && !a.phase_hist && a.pair_op == 0) {
+            const BusPlan plan = plan_voice_bus(a, KIND);
+            if (plan.steady) {
+                a.span = plan.span;
+                a.steady = 1;
+                const int err = launch_steady<false, C, true>(a, bus, plan.vpt, out, out_ld, stream);
+                if (err || bus.out) return err;
+                const int tiles_s = (a.voices + SIG_WAVE * plan.vpt - 1) / (SIG_WAVE * plan.vpt);
+                return sig_bus::launch_partials<C>(bus.partials, tiles_s, bus.rows, out, out_ld, stream);
+            }
+        }
+    }
     auto ok = [&](int vpt) {
         return C > 0 || ((a.voices % vpt == 0) && (a.out_ld % vpt == 0) && (reinterpret_cast<uintptr_t>(a.out) % (vpt * 4) == 0));
     };
@@ -894,7 +927,6 @@ int dispatch_rows_kind(int kind, const FusedArgs& a, const BusArgs& bus, float* 
 // What sig_fused_voice_bus launches for this problem: voices per lane, blocks per lane, and whether the Sine closed
 // form (fused_steady_bus_kernel) takes the launch.  One decision function for the launcher and for
 // sig_fused_voice_bus_plan (tests and bench.py name the kernel they time with it).
-struct BusPlan { int vpt, span, steady; };
 BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
     BusPlan p{4, 1, 0};
     pick_geometry(a, 4, p.vpt, p.span);
@@ -922,6 +954,29 @@ BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
     return p;
 }
 
+// the closed form: per-voice constants, then one launch (closed form per wave, or its built-in plain fallback
+// steady_fallback_span); sets bus.out when the kernel adds the voice tiles itself
+template <bool GAIN, int C, bool GROWS>
+int launch_steady(FusedArgs& a, BusArgs& bus, int vpt, float* out, int64_t out_ld, hipStream_t stream)
+{
+    double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
+    a.steady_consts = consts;
+    if (!(a.consts_ext && a.consts_ready))
+        steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+    a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
+    const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (sig_bus::tiles_sum_in_workgroup(a.voice_tiles) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
+    switch (vpt) {
+        case 1: fused_steady_bus_kernel<1, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 2: fused_steady_bus_kernel<2, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 8: fused_steady_bus_kernel<8, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 16: fused_steady_bus_kernel<16, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        default: fused_steady_bus_kernel<4, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+    }
+    return sig_launch_status();
+}
+
 template <int KIND, bool GAIN, int C>
 int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
@@ -930,23 +985,7 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
     a.span = plan.span;
     a.steady = plan.steady;
     if (a.steady) {
-        // per-voice constants, then one launch: closed form per wave, or its built-in plain fallback (steady_fallback_span)
-        double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
-        a.steady_consts = consts;
-        if (!(a.consts_ext && a.consts_ready))
-            steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
-        a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
-        const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
-        if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-        if (sig_bus::tiles_sum_in_workgroup(a.voice_tiles) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
-        switch (vpt) {
-            case 1: fused_steady_bus_kernel<1, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            case 2: fused_steady_bus_kernel<2, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            case 8: fused_steady_bus_kernel<8, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            case 16: fused_steady_bus_kernel<16, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-            default: fused_steady_bus_kernel<4, C><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        }
-        const int e2 = sig_launch_status();
+        const int e2 = launch_steady<GAIN, C, false>(a, bus, vpt, out, out_ld, stream);
         if (e2 || bus.out) return e2;                                          // (the kernel added the voice tiles itself)
     } else {                                                                   // (Sine with the closed form: that launch did every wave)
         const int tiles_w = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);

@@ -174,6 +174,7 @@ class BatchRenderer:
         self._tails: dict[Emitter, tuple[int, torch.Tensor]] = {}    # node -> (end position, last <=100 rows)
         self._stream_end: int | None = None
         self._ctl_programs: dict = {}                      # compiled block-rate control programs, by (port sources, K)
+        self._tremolo_order = None                         # (key, held tensors, index, ordered constant rows, ordered pan) of a tremolo-only Sine voice
         self._prev_block_frames: int | None = None         # N of the previous render (where a fused cascade's history block starts)
         self._virtual_history = False                      # the previous batch kept its filter history implicit (no tails needed)
         self._cascade_stream = False                       # ... and this batch continues it
@@ -1101,13 +1102,22 @@ class _VoiceChain:
         over voices, so any order renders the same bus up to the rounding of the sum; this one lets the Sine closed
         form drop the decayed homogeneous part of whole voice slots (fused_voice.hip: fused_steady_bus_kernel).
         Built once per parameter upload (it is kept with the closed form's constants)."""
+        index = self.cutoff_order(ctl, voices_per_lane)
+        if index is None:
+            return ctl, pan
+        v = self.channels
+        pick = lambda t: t if t is None or t.shape[1] != v else t.index_select(1, index).contiguous()
+        return [pick(t) for t in ctl], pick(pan)
+
+    def cutoff_order(self, ctl, voices_per_lane: int):
+        """the permutation of `ordered_by_cutoff` as a device index, or None when the cutoffs are not one Fixed row"""
         import numpy as np
         v, src = self.channels, self.filt.cutoff.sig
         if ctl[2].shape[1] != v or not isinstance(src, fixed.Fixed):
-            return ctl, pan
+            return None
         cut = np.asarray(src._state.value, dtype=np.float64).reshape(-1)
         if cut.size != v or not np.isfinite(cut).all():
-            return ctl, pan
+            return None
         order = np.argsort(cut, kind='stable')
         tile = 64 * voices_per_lane
         tiles = v // tile
@@ -1117,9 +1127,7 @@ class _VoiceChain:
         # of slow- and fast-decaying slots (one wave per SIMD: the launch takes as long as its slowest wave)
         group, lane = q // 64, q % 64
         perm[((group % tiles) * 64 + lane) * voices_per_lane + group // tiles] = order[q]
-        index = torch.from_numpy(perm).to(runtime.device())
-        pick = lambda t: t if t is None or t.shape[1] != v else t.index_select(1, index).contiguous()
-        return [pick(t) for t in ctl], pick(pan)
+        return torch.from_numpy(perm).to(runtime.device())
 
     def live_key(self, bus_node=None):
         """identities of the resident control tensors (and the bus gains) as they are NOW -- `resident()` re-uploads an
@@ -1209,6 +1217,21 @@ class _VoiceChain:
         if self.general:
             if bus_c not in (1, 2):
                 return None
+            if (self.kind == 'Sine' and self.pair is None and not self.fm and controls[2].shape[0] == 1
+                    and controls[3] is not None and controls[3].shape[0] > 1 and controls[3].shape[1] == v):
+                # a tremolo is the only modulation: sig_fused_voice_bus_rows keeps the closed form for it, and the closed form
+                # wants its voices ordered by cutoff (ordered_by_cutoff); the order is kept while the constant rows are
+                held = o._tremolo_order
+                key = (id(controls[0]), id(controls[1]), id(controls[2]), id(pan), K)
+                if held is None or held[0] != key:
+                    plan = _native.fused_voice_bus_plan('Sine', b.pos, v, N, K, CONTEXT)
+                    index = self.cutoff_order(controls, plan['voices_per_lane']) if plan['closed_form'] else None
+                    pick = lambda t: t if t is None or index is None or t.shape[1] != v else t.index_select(1, index).contiguous()
+                    held = o._tremolo_order = (key, (controls[0], controls[1], controls[2], pan), index,
+                                               [pick(controls[0]), pick(controls[1]), pick(controls[2])], pick(pan))
+                if held[2] is not None:
+                    controls = held[3] + [controls[3].index_select(1, held[2])]
+                    pan = held[4]
             out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
             return o._launch(f'fused_voice_bus[{self.tag}]',
                              lambda: _native.fused_rows(self.kind, self.btype, rate, b.pos, N, K, CONTEXT, v, controls[0], controls[1],

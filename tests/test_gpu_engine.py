@@ -812,6 +812,52 @@ def test_lfo_swept_cutoff_and_tremolo_run_in_the_fused_chain(golden):
                 assert maxerr(got, eager) < 1e-6, (kind, bus, tremolo)
 
 
+def test_tremolo_only_sine_voice_keeps_the_closed_form(golden):
+    """a Sine voice whose only block-rate parameter is its gain (a tremolo) runs the closed-form kernel with the bus weights
+    rebuilt at every block's first row (fused_steady_bus_kernel<.., GROWS>) instead of the row walker: same answer as the
+    walker (tuning hook) and the oracle, batches of 5 + 3 + 1 blocks, mono and stereo, voices that take the kernel's plain
+    fallback among them"""
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('c2')
+    V, N = 32, 256
+    hz, ph, cut, gain = g['c2/hertz'][:, :V].copy(), g['c2/phase'][:, :V], g['c2/cutoff'][:, :V], g['c2/gain'][:, :V]
+    hz[0, 3] = 2.0                                                      # below the closed form's range: that wave falls back
+    th = np.random.default_rng(8).uniform(0, np.pi / 2, V)
+    pan = np.stack([np.cos(th), np.sin(th)])
+
+    def build(stereo):
+        trem = fx.Mix(); trem.left = mkosc('Triangle', [[3.1]]); trem.right = fix([[1.0]]); trem.mix = fix([[0.3]])
+        depth = fx.RingMod(); depth.left = trem; depth.right = fix(gain)
+        f = fx.LowPass(); f.input = mkosc('Sine', hz, ph); f.cutoff = fix(cut)
+        top = fx.Gain(); top.left = f; top.right = depth
+        b = ext.SumBus(); b.input = top
+        if stereo:
+            b.get_state().gains = np.ascontiguousarray(pan)
+        return b
+
+    trem = R.Binary('Mix', R.Osc('Triangle', R.Fixed([[3.1]])), R.Fixed([[1.0]]), R.Fixed([[0.3]]))
+    node = R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), R.Fixed(cut)), R.Binary('RingMod', trem, R.Fixed(gain)))
+    try:
+        for stereo in (False, True):
+            ref = R.sum_bus(R.render_stream(node, 4096, N, 9, V), pan if stereo else None)
+            outs = {}
+            for steady in (1, 0):
+                _native.set_fused_tuning(0, 0, steady, 0)
+                timer = KernelTimer()
+                r = BatchRenderer(build(stereo), 2 if stereo else 1, RATE, timer=timer)
+                outs[steady] = np.concatenate([r.render(4096, N, 5).cpu().numpy(), r.render(4096 + 5 * N, N, 3).cpu().numpy(),
+                                               r.render(4096 + 8 * N, N, 1).cpu().numpy()])
+                torch.cuda.synchronize()
+                assert any(n.startswith('fused_voice_bus[Sine,lp,gain,per-block]') for n in timer.summary()), set(timer.summary())
+                assert maxerr(outs[steady], f32(ref)) < 1e-6, (stereo, steady)
+            assert maxerr(outs[1], outs[0]) < 2e-7, stereo
+    finally:
+        _native.set_fused_tuning()
+
+
 def test_control_program_equals_the_node_by_node_evaluation_bit_for_bit():
     """sig_control_program: a block-rate control subgraph (oscillators of every waveform, Gain / Mix / RingMod / Amp, Fixed rows
     one column or V wide, shared sub-expressions, an unplugged port, a disabled node) compiled into one launch gives the
