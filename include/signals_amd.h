@@ -215,7 +215,9 @@ int sig_fused_voice_bus_rows(int osc_kind, int filt_type, int32_t rate, int64_t 
 /* ... and with hertz and phase read per block as well: block-rate frequency / phase modulation (Osc._eval reads both
  * ports with forward_at_block_rate, osc.py:28-30).  hertz_rows / phase_rows: 1 or nblocks, rows laid out like cutoff's.
  * The reference's oscillators keep their previous block (BlockCachingEmitter, chain/__init__.py:424-442), so the context
- * rows a filter sees in front of block b are block b - 1's samples, made with parameter row b - 1: the walker's
+ * rows a filter sees in front of block b are block b - 1's samples (block_frames >= context: with shorter blocks the
+ * reference answers the context request as a block of its own -- not this entry point's semantics, callers keep such graphs
+ * on the per-node path), made with parameter row b - 1: the walker's
  * warm-up chain already runs on the samples at hand.  For the launch's first block that row is *_hist (one (1,V)|(1,1)
  * row, same stride; non-NULL marks the parameter as modulated -- also in a one-block launch, whose single row still has a
  * different row in front; required when the matching *_rows > 1): the previous batch's last row on a continuing stream, the

@@ -1012,8 +1012,12 @@ class _VoiceChain:
                 pair, src = (src, right), left
         if not isinstance(src, osc.Osc) or not src.get_state().enabled or len(src.outputs_with_ports) != 1:
             return None
-        if pair is not None and not (_ctl_const(src.hertz) and _ctl_const(src.phase)):
-            return None                                             # (two oscillators AND block-rate FM: per node)
+        fm = not (_ctl_const(src.hertz) and _ctl_const(src.phase))
+        if fm and (pair is not None or batch.N < CONTEXT):
+            # two oscillators AND block-rate FM: per node.  Blocks shorter than the context: the context request [p - 100, p) is
+            # then contained in no single cached block of the oscillator, so the reference answers it as a block of its own
+            # (controls read at p - 100) -- not the previous block's samples the fused walker warms up on: per node too
+            return None
         chain = cls(batch, src, filt, gain_node, bus_node, channels, pre_gain, pair)
         controls = chain.resolve()
         if controls is None or not chain.widths_ok(controls):

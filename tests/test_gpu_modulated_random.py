@@ -1,0 +1,99 @@
+"""Random modulated voices against the CPU oracle: any waveform, low / high pass, every subset of {hertz, phase, cutoff,
+gain} driven by a block-rate LFO (RingMod(Mix(Osc, 1, depth), centre row)), with or without a gain stage and a mono / stereo
+bus, ragged voice counts, streams in three batches from positions 0 / 37 / 4096 / one minute -- the fused walker with
+per-block rows, block-rate FM and its row in front of the batch, the tremolo-only closed form, the control program and the
+in-kernel tile sums all behind the engine's default schedule.  Blocks shorter than the filter context with a modulated
+oscillator are not batchable (the reference then answers the context request as a block of its own): the engine must say
+so rather than render something else."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RATE, f32, fix, maxerr, mkosc
+
+pytestmark = pytest.mark.gpu
+KINDS = ['Sine', 'Sawtooth', 'Square', 'Triangle']
+
+
+def draw(rng):
+    V = int(rng.choice([8, 64, 70, 130, 256, 520]))
+    N = int(rng.choice([64, 128, 256, 512]))
+    mods = {k: bool(rng.integers(0, 2)) for k in ('hertz', 'phase', 'cutoff', 'gain')}
+    th = rng.uniform(0, np.pi / 2, V)
+    return dict(V=V, N=N, kind=str(rng.choice(KINDS)), btype=str(rng.choice(['lp', 'hp'])), mods=mods,
+                use_gain=mods['gain'] or bool(rng.integers(0, 2)), bus=int(rng.choice([0, 1, 2])),
+                start=int(rng.choice([0, 37, 4096, 48000 * 60])), batches=[int(x) for x in rng.choice([1, 2, 3, 5, 9], size=3)],
+                hz=rng.uniform(40, 3000, (1, V)), ph=rng.uniform(0, 1, (1, V)), cut=rng.uniform(100, 9000, (1, V)),
+                gain=rng.uniform(0.1, 1.0, (1, V)), pan=np.stack([np.cos(th), np.sin(th)]),
+                lf={k: (float(rng.uniform(0.3, 9.0)), str(rng.choice(KINDS)), float(rng.uniform(0.05, 0.4))) for k in mods})
+
+
+def build(c):
+    from signals_amd.chain import ext, fx
+
+    def lfo(k, centre):
+        f_, kd, depth = c['lf'][k]
+        m = fx.Mix(); m.left = mkosc(kd, [[f_]]); m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r_ = fx.RingMod(); r_.left = m; r_.right = fix(centre)
+        return r_
+    o = mkosc(c['kind'], c['hz'], c['ph'])
+    if c['mods']['hertz']:
+        o.hertz = lfo('hertz', c['hz'])
+    if c['mods']['phase']:
+        o.phase = lfo('phase', c['ph'])
+    f = getattr(fx, 'LowPass' if c['btype'] == 'lp' else 'HighPass')(); f.input = o
+    f.cutoff = lfo('cutoff', c['cut']) if c['mods']['cutoff'] else fix(c['cut'])
+    top = f
+    if c['use_gain']:
+        g = fx.Gain(); g.left = f; g.right = lfo('gain', c['gain']) if c['mods']['gain'] else fix(c['gain'])
+        top = g
+    if c['bus']:
+        b = ext.SumBus(); b.input = top
+        if c['bus'] == 2:
+            b.get_state().gains = np.ascontiguousarray(c['pan'])
+        top = b
+    return top
+
+
+def oracle(c):
+    from oracle import chain_ref as R
+
+    def lfo(k, centre):
+        f_, kd, depth = c['lf'][k]
+        return R.Binary('RingMod', R.Binary('Mix', R.Osc(kd, R.Fixed([[f_]])), R.Fixed([[1.0]]), R.Fixed([[depth]])), R.Fixed(centre))
+    o = R.Osc(c['kind'], lfo('hertz', c['hz']) if c['mods']['hertz'] else R.Fixed(c['hz']),
+              lfo('phase', c['ph']) if c['mods']['phase'] else R.Fixed(c['ph']))
+    node = R.Filter(c['btype'], o, lfo('cutoff', c['cut']) if c['mods']['cutoff'] else R.Fixed(c['cut']))
+    if c['use_gain']:
+        node = R.Binary('Gain', node, lfo('gain', c['gain']) if c['mods']['gain'] else R.Fixed(c['gain']))
+    return node
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_random_modulated_voices_against_the_oracle(seed):
+    from oracle import chain_ref as R
+    from signals_amd.engine import BatchRenderer, NotBatchable
+    rng = np.random.default_rng(seed)
+    rendered = refused = 0
+    for case in range(24):
+        c = draw(rng)
+        V, N = c['V'], c['N']
+        r = BatchRenderer(build(c), c['bus'] if c['bus'] else V, RATE)
+        fm_short = (c['mods']['hertz'] or c['mods']['phase']) and N < 100
+        pos, parts = c['start'], []
+        try:
+            for k in c['batches']:
+                parts.append(r.render(pos, N, k).cpu().numpy())
+                pos += N * k
+        except NotBatchable:
+            assert fm_short, (seed, case)
+            refused += 1
+            continue
+        assert not fm_short, (seed, case)
+        ref = R.render_stream(oracle(c), c['start'], N, sum(c['batches']), V)
+        if c['bus']:
+            ref = R.sum_bus(ref, c['pan'] if c['bus'] == 2 else None)
+        err = maxerr(np.concatenate(parts), f32(ref))
+        assert err < 2e-6 * max(1.0, float(np.abs(ref).max())), (seed, case, c['kind'], c['btype'], V, N, c['start'], c['batches'], c['mods'], c['bus'], err)
+        rendered += 1
+    assert rendered >= 12 and refused >= 1, (rendered, refused)
