@@ -1212,7 +1212,8 @@ bool pair_ok(const PairSource& p) {
 }
 // block-rate FM (sig_fused_*_fm): hertz / phase rows per block + the row in front of the launch
 struct FmSource { int hertz_rows = 1, phase_rows = 1; const double* hertz_hist = nullptr; const double* phase_hist = nullptr; };
-bool fm_ok(const FmSource& f, int nblocks, const double* phase) {
+bool fm_ok(const FmSource& f, int nblocks, const double* phase, int block_frames, int context) {
+    if ((f.hertz_hist || f.phase_hist) && block_frames < context) return false;   // (the context of a shorter block is not the previous block's samples)
     return (f.hertz_rows == 1 || (f.hertz_rows == nblocks && f.hertz_hist)) &&
            (f.phase_rows == 1 || (f.phase_rows == nblocks && f.phase_hist)) && (!f.phase_hist || phase);
 }
@@ -1232,7 +1233,7 @@ int fused_chain_general(int osc_kind, int filt_type, int32_t rate, int64_t posit
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices && pair_ok(pair) && fm_ok(fm, nblocks, phase));
+    SIG_CHECK_ARG(hertz && cutoff && out && out_ld >= voices && pair_ok(pair) && fm_ok(fm, nblocks, phase, block_frames, context));
     SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
     SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
     if (block_frames == 0 || nblocks == 0 || voices == 0) return 0;
@@ -1254,7 +1255,7 @@ int fused_bus_general(int osc_kind, int filt_type, int32_t rate, int64_t positio
 {
     SIG_CHECK_ARG(filt_type == SIG_FILT_LOWPASS || filt_type == SIG_FILT_HIGHPASS);
     SIG_CHECK_ARG(rate > 0 && position >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && voices >= 0);
-    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels && pair_ok(pair) && fm_ok(fm, nblocks, phase));
+    SIG_CHECK_ARG(hertz && cutoff && out && workspace && out_ld >= bus_channels && pair_ok(pair) && fm_ok(fm, nblocks, phase, block_frames, context));
     SIG_CHECK_ARG((hertz_stride | 1) == 1 && (phase_stride | 1) == 1 && (cutoff_stride | 1) == 1 && (gain_stride | 1) == 1);
     SIG_CHECK_ARG((cutoff_rows == 1 || cutoff_rows == nblocks) && (gain_rows == 1 || gain_rows == nblocks));
     SIG_CHECK_ARG(bus_gains ? bus_gains_ld >= voices : bus_channels == 1);
