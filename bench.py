@@ -617,8 +617,8 @@ def main():
 
     if rank == 0:
         def describe(fused):
-            return ('fused voice chain + bus: sig_fused_voice_bus (Sine->LowPass->Gain->SumBus in one chain launch plus a '
-                    'fixed-order tile sum; no per-voice sample touches HBM)' if fused else
+            return ('fused voice chain + bus: sig_fused_voice_bus (Sine->LowPass->Gain->SumBus in ONE launch, its voice tiles '
+                    'added in fixed order by the same kernel; no per-voice sample touches HBM)' if fused else
                     'node-materialised: one kernel per node (osc_bank, biquad_coldstart, elementwise[Gain], sum_bus), '
                     'every edge f32 in HBM (24 B/voice-sample, SURVEY.md 8d)')
         line = {
