@@ -318,6 +318,10 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 1.0) -> dict:
                             'achieved': 768 * V * N * K / secs / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s (bf16, dense)',
                             'frac': 768 * V * N * K / secs / 1e12 / 2500.0,
                             'instruction': 'v_mfma_f32_32x32x16_bf16, 48 per 32-row x 64-voice tile'}
+            extra_c5 = {'contraction': 'float32 rows x float32 matrix, float32 accumulators; products exact: each float32 operand is the sum of '
+                                       'three bfloat16 (six v_mfma_f32_32x32x16_bf16 terms per k-block, the three below 2^-26 dropped); measured '
+                                       'against the f64 product of the same rows: 2.3-4.8 ulp of the rows\' scale, v_mfma_f32_32x32x2_f32 2.8-5.3 '
+                                       '(tests/test_gpu_fused_walker.py); f32_mfma_sink times the same launch on that instruction'}
             roof['store_rate_of_a_plain_fill_GBs'] = 6900.0     # torch fill_ of 256 MiB on this GPU (tools/ubench/torch_bandwidth.py): the practical write roof
     full_scale = float(np.max(np.abs(ref)))
     extra = {}
@@ -345,6 +349,8 @@ def run_config(name: str, steps: int = 0, prewarm_s: float = 1.0) -> dict:
                                       'instruction': 'v_mfma_f32_32x32x2_f32, 64 per 32-row x 64-voice tile'}
         finally:
             _native.set_fused_tuning()
+    if name == 'C5':
+        extra.update(extra_c5)
     return {**extra, 'workload': workload, 'value': V * N * K * steps / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt / steps * 1e3,
             'steps': steps, 'roofline': roof, 'kernels': kernels,
             'max_abs_error': {'per_block': errs, 'max': max(errs.values()), 'full_scale': full_scale,
