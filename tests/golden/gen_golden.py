@@ -274,6 +274,54 @@ def gen_cascade(out):
     out['casc/fresh_p768'] = render(f2, 768, 256, V)
 
 
+def gen_modulated(out):
+    """Control ports driven at block rate (forward_at_block_rate, chain/__init__.py:305-306): vibrato on an oscillator's
+    hertz, a wobble on its phase, an LFO sweep on a filter's cutoff, a tremolo on a gain -- rendered sequentially, so that
+    a filter's context rows are what the oscillator's block cache answers (the previous block's samples when the block is
+    at least as long as the context; a block of its own at p - 100 when it is shorter: N = 64)."""
+    V = 8
+    vp = voice_params(V, seed=2)
+    cut = np.geomspace(200, 7000, V).reshape(1, V)
+    gain = np.linspace(0.2, 1.0, V).reshape(1, V)
+    for k, v in (('hertz', vp['hertz']), ('phase', vp['phase']), ('cutoff', cut), ('gain', gain)):
+        out[f'mod/{k}'] = v
+
+    def lfo(kind, hz, depth, centre):
+        """centre * (1 - depth + depth * osc)  as  RingMod(Mix(osc, 1, depth), centre)"""
+        o = OSC[kind]()
+        o.hertz = fix([[hz]])
+        m = fx.Mix()
+        m.left = o
+        m.right = fix([[1.0]])
+        m.mix = fix([[depth]])
+        r = fx.RingMod()
+        r.left = m
+        r.right = fix(centre)
+        return r
+
+    def voice(kind, fm, pm, sweep, trem):
+        o = OSC[kind]()
+        o.hertz = lfo('Sine', 5.3, 0.02, vp['hertz']) if fm else fix(vp['hertz'])
+        o.phase = lfo('Triangle', 2.1, 0.1, vp['phase']) if pm else fix(vp['phase'])
+        f = fx.LowPass()
+        f.input = o
+        f.cutoff = lfo('Sine', 1.7, 0.4, cut) if sweep else fix(cut)
+        g = fx.Gain()
+        g.left = f
+        g.right = lfo('Triangle', 3.1, 0.3, gain) if trem else fix(gain)
+        return g
+
+    cases = {'fm': ('Sawtooth', True, False, False, False), 'fm_pm_sine': ('Sine', True, True, False, False),
+             'sweep_trem': ('Square', False, False, True, True), 'all': ('Triangle', True, True, True, True),
+             'trem_sine': ('Sine', False, False, False, True)}
+    for name, spec in cases.items():
+        for N, blocks, start in ((256, 5, 0), (256, 4, 4096), (64, 6, 4096)):
+            p = Probe()
+            p.input = voice(*spec)
+            out[f'mod/{name}/n{N}_p{start}'] = np.concatenate(
+                [np.array(p.input.request(loc(start + b * N, N, V))) for b in range(blocks)])
+
+
 def gen_effects(out):
     V, N, pos = 8, 128, 300
     vp = voice_params(V, seed=2)
@@ -399,7 +447,7 @@ def gen_blockloc(out):
 def main():
     groups = {
         'osc': gen_osc, 'filter': gen_filter, 'cascade': gen_cascade, 'effects': gen_effects,
-        'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc,
+        'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc, 'modulated': gen_modulated,
     }
     meta = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                 rate=RATE, reference='/root/reference (noah-aviel-dove/signals @ v1)',

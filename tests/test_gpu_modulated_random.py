@@ -97,3 +97,50 @@ def test_random_modulated_voices_against_the_oracle(seed):
         assert err < 2e-6 * max(1.0, float(np.abs(ref).max())), (seed, case, c['kind'], c['btype'], V, N, c['start'], c['batches'], c['mods'], c['bus'], err)
         rendered += 1
     assert rendered >= 12 and refused >= 1, (rendered, refused)
+
+
+GOLDEN_CASES = {'fm': ('Sawtooth', True, False, False, False), 'fm_pm_sine': ('Sine', True, True, False, False),
+                'sweep_trem': ('Square', False, False, True, True), 'all': ('Triangle', True, True, True, True),
+                'trem_sine': ('Sine', False, False, False, True)}
+
+
+@pytest.mark.parametrize('name', sorted(GOLDEN_CASES))
+def test_modulated_voices_against_the_reference_fixtures(golden, name):
+    """the engine's default schedule against outputs of the REFERENCE itself (tests/golden/modulated.npz): vibrato, phase
+    wobble, cutoff sweep and tremolo voices rendered sequentially, 256-frame blocks from 0 and from 4096; 64-frame blocks
+    (shorter than the filter context) where the oscillator is not modulated, and a refusal where it is"""
+    from signals_amd.chain import fx
+    from signals_amd.engine import BatchRenderer, KernelTimer, NotBatchable
+    g = golden('modulated')
+    kind, fm, pm, sweep, trem = GOLDEN_CASES[name]
+
+    def lfo(k, hz, depth, centre):
+        m = fx.Mix(); m.left = mkosc(k, [[hz]]); m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r_ = fx.RingMod(); r_.left = m; r_.right = fix(centre)
+        return r_
+
+    def build():
+        o = mkosc(kind, g['mod/hertz'], g['mod/phase'])
+        if fm:
+            o.hertz = lfo('Sine', 5.3, 0.02, g['mod/hertz'])
+        if pm:
+            o.phase = lfo('Triangle', 2.1, 0.1, g['mod/phase'])
+        f = fx.LowPass(); f.input = o
+        f.cutoff = lfo('Sine', 1.7, 0.4, g['mod/cutoff']) if sweep else fix(g['mod/cutoff'])
+        top = fx.Gain(); top.left = f
+        top.right = lfo('Triangle', 3.1, 0.3, g['mod/gain']) if trem else fix(g['mod/gain'])
+        return top
+
+    V = g['mod/hertz'].shape[1]
+    for N, blocks, start in ((256, 5, 0), (256, 4, 4096), (64, 6, 4096)):
+        ref = g[f'mod/{name}/n{N}_p{start}']
+        timer = KernelTimer()
+        r = BatchRenderer(build(), V, RATE, timer=timer)
+        if (fm or pm) and N < 100:
+            with pytest.raises(NotBatchable):
+                r.render(start, N, blocks)
+            continue
+        got = np.concatenate([r.render(start, N, 2).cpu().numpy(), r.render(start + 2 * N, N, blocks - 2).cpu().numpy()])
+        torch.cuda.synchronize()
+        assert any(n.startswith('fused_osc_biquad[') for n in timer.summary()), set(timer.summary())
+        assert maxerr(got, f32(ref)) < 1e-6, (name, N, start)

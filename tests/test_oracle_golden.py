@@ -187,6 +187,37 @@ def test_c2_reduced(golden, tag, pos0):
     assert same(R.render_stream(n, pos0, 256, 4, 32), g[f'c2/{tag}'])
 
 
+MOD_CASES = {'fm': ('Sawtooth', True, False, False, False), 'fm_pm_sine': ('Sine', True, True, False, False),
+             'sweep_trem': ('Square', False, False, True, True), 'all': ('Triangle', True, True, True, True),
+             'trem_sine': ('Sine', False, False, False, True)}
+
+
+def modulated_voice(g, spec):
+    """the oracle graph of tests/golden/gen_golden.py: gen_modulated"""
+    kind, fm, pm, sweep, trem = spec
+
+    def lfo(k, hz, depth, centre):
+        return R.Binary('RingMod', R.Binary('Mix', R.Osc(k, R.Fixed([[hz]])), R.Fixed([[1.0]]), R.Fixed([[depth]])), R.Fixed(centre))
+    hertz = lfo('Sine', 5.3, 0.02, g['mod/hertz']) if fm else R.Fixed(g['mod/hertz'])
+    phase = lfo('Triangle', 2.1, 0.1, g['mod/phase']) if pm else R.Fixed(g['mod/phase'])
+    cutoff = lfo('Sine', 1.7, 0.4, g['mod/cutoff']) if sweep else R.Fixed(g['mod/cutoff'])
+    gain = lfo('Triangle', 3.1, 0.3, g['mod/gain']) if trem else R.Fixed(g['mod/gain'])
+    return R.Binary('Gain', R.Filter('lp', R.Osc(kind, hertz, phase), cutoff), gain)
+
+
+@pytest.mark.parametrize('name', sorted(MOD_CASES))
+def test_block_rate_modulated_voices(golden, name):
+    """control ports driven at block rate, rendered sequentially by the REFERENCE: vibrato, phase wobble, cutoff sweep,
+    tremolo.  Pins what a filter's context rows are under a modulated oscillator -- the oscillator's cached previous block
+    when the block is at least as long as the context (N = 256), a block of its own read at p - 100 when it is shorter
+    (N = 64: the request is contained in no single cached block) -- which is what the fused FM path builds on"""
+    g = golden('modulated')
+    for N, blocks, start in ((256, 5, 0), (256, 4, 4096), (64, 6, 4096)):
+        ref = g[f'mod/{name}/n{N}_p{start}']
+        got = R.render_stream(modulated_voice(g, MOD_CASES[name]), start, N, blocks, ref.shape[1])
+        assert same(got, ref), (name, N, start, float(np.abs(got - ref).max()))
+
+
 def test_blockloc_table(golden):
     for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
         assert R.before(int(pos), int(n), 100) == (bp, bf)
