@@ -322,6 +322,51 @@ def gen_modulated(out):
                 [np.array(p.input.request(loc(start + b * N, N, V))) for b in range(blocks)])
 
 
+def gen_pairs(out):
+    """A filter reading TWO oscillators through Mix / RingMod (fx.py:35-46), and a Gain in front of a filter: the
+    topologies round 2's fuser folds into one launch; rendered sequentially."""
+    V, N = 8, 256
+    vp, vq = voice_params(V, seed=3), voice_params(V, seed=4)
+    cut = np.geomspace(200, 7000, V).reshape(1, V)
+    m = np.linspace(0.1, 0.9, V).reshape(1, V)
+    for k, v in (('hertz', vp['hertz']), ('phase', vp['phase']), ('hertz2', vq['hertz'] * 0.5), ('phase2', vq['phase']),
+                 ('cutoff', cut), ('mix', m)):
+        out[f'pair/{k}'] = v
+
+    def two(ka, kb):
+        a = OSC[ka]()
+        a.hertz = fix(vp['hertz'])
+        a.phase = fix(vp['phase'])
+        b = OSC[kb]()
+        b.hertz = fix(vq['hertz'] * 0.5)
+        b.phase = fix(vq['phase'])
+        return a, b
+
+    for op, ka, kb in (('Mix', 'Sine', 'Sawtooth'), ('RingMod', 'Triangle', 'Square'), ('Mix', 'Sawtooth', 'Sine')):
+        a, b = two(ka, kb)
+        e = getattr(fx, op)()
+        e.left = a
+        e.right = b
+        if op == 'Mix':
+            e.mix = fix(m)
+        f = fx.LowPass()
+        f.input = e
+        f.cutoff = fix(cut)
+        p = Probe()
+        p.input = f
+        out[f'pair/{op}_{ka}_{kb}'] = np.concatenate([np.array(p.input.request(loc(4096 + b_ * N, N, V))) for b_ in range(3)])
+    a, _ = two('Triangle', 'Sine')
+    g = fx.Gain()
+    g.left = a
+    g.right = fix(m)
+    f = fx.HighPass()
+    f.input = g
+    f.cutoff = fix(cut)
+    p = Probe()
+    p.input = f
+    out['pair/pre_gain_Triangle_hp'] = np.concatenate([np.array(p.input.request(loc(b_ * N, N, V))) for b_ in range(3)])
+
+
 def gen_effects(out):
     V, N, pos = 8, 128, 300
     vp = voice_params(V, seed=2)
@@ -447,7 +492,7 @@ def gen_blockloc(out):
 def main():
     groups = {
         'osc': gen_osc, 'filter': gen_filter, 'cascade': gen_cascade, 'effects': gen_effects,
-        'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc, 'modulated': gen_modulated,
+        'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc, 'modulated': gen_modulated, 'pairs': gen_pairs,
     }
     meta = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                 rate=RATE, reference='/root/reference (noah-aviel-dove/signals @ v1)',

@@ -144,3 +144,30 @@ def test_modulated_voices_against_the_reference_fixtures(golden, name):
         torch.cuda.synchronize()
         assert any(n.startswith('fused_osc_biquad[') for n in timer.summary()), set(timer.summary())
         assert maxerr(got, f32(ref)) < 1e-6, (name, N, start)
+
+
+def test_two_oscillator_and_pre_gain_voices_against_the_reference_fixtures(golden):
+    """tests/golden/pairs.npz (outputs of the reference): Filter(Mix | RingMod(Osc, Osc)) and Filter(Gain(Osc)) through the
+    engine's default schedule -- one fused launch each"""
+    from signals_amd.chain import fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    g = golden('pairs')
+    V = g['pair/hertz'].shape[1]
+    for op, ka, kb in (('Mix', 'Sine', 'Sawtooth'), ('RingMod', 'Triangle', 'Square'), ('Mix', 'Sawtooth', 'Sine')):
+        e = getattr(fx, op)(); e.left = mkosc(ka, g['pair/hertz'], g['pair/phase']); e.right = mkosc(kb, g['pair/hertz2'], g['pair/phase2'])
+        if op == 'Mix':
+            e.mix = fix(g['pair/mix'])
+        f = fx.LowPass(); f.input = e; f.cutoff = fix(g['pair/cutoff'])
+        timer = KernelTimer()
+        r = BatchRenderer(f, V, RATE, timer=timer)
+        got = np.concatenate([r.render(4096, 256, 1).cpu().numpy(), r.render(4096 + 256, 256, 2).cpu().numpy()])
+        torch.cuda.synchronize()
+        assert [n.split('[')[0] for n in timer.summary()] == ['fused_osc_biquad'], set(timer.summary())
+        assert maxerr(got, f32(g[f'pair/{op}_{ka}_{kb}'])) < 1e-6, (op, ka, kb)
+    gn = fx.Gain(); gn.left = mkosc('Triangle', g['pair/hertz'], g['pair/phase']); gn.right = fix(g['pair/mix'])
+    f = fx.HighPass(); f.input = gn; f.cutoff = fix(g['pair/cutoff'])
+    timer = KernelTimer()
+    got = BatchRenderer(f, V, RATE, timer=timer).render(0, 256, 3).cpu().numpy()
+    torch.cuda.synchronize()
+    assert [n.split('[')[0] for n in timer.summary()] == ['fused_osc_biquad'], set(timer.summary())
+    assert maxerr(got, f32(g['pair/pre_gain_Triangle_hp'])) < 1e-6

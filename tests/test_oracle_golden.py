@@ -218,6 +218,29 @@ def test_block_rate_modulated_voices(golden, name):
         assert same(got, ref), (name, N, start, float(np.abs(got - ref).max()))
 
 
+PAIR_CASES = (('Mix', 'Sine', 'Sawtooth'), ('RingMod', 'Triangle', 'Square'), ('Mix', 'Sawtooth', 'Sine'))
+
+
+def pair_voice(g, op, ka, kb):
+    a = R.Osc(ka, R.Fixed(g['pair/hertz']), R.Fixed(g['pair/phase']))
+    b = R.Osc(kb, R.Fixed(g['pair/hertz2']), R.Fixed(g['pair/phase2']))
+    e = R.Binary('Mix', a, b, R.Fixed(g['pair/mix'])) if op == 'Mix' else R.Binary('RingMod', a, b)
+    return R.Filter('lp', e, R.Fixed(g['pair/cutoff']))
+
+
+def test_two_oscillator_and_pre_gain_voices(golden):
+    """a filter reading Mix / RingMod of two oscillators, and Gain in front of a filter, rendered sequentially by the
+    REFERENCE: the topologies the fuser folds into one launch"""
+    g = golden('pairs')
+    for op, ka, kb in PAIR_CASES:
+        ref = g[f'pair/{op}_{ka}_{kb}']
+        assert same(R.render_stream(pair_voice(g, op, ka, kb), 4096, 256, 3, ref.shape[1]), ref), (op, ka, kb)
+    pre = R.Filter('hp', R.Binary('Gain', R.Osc('Triangle', R.Fixed(g['pair/hertz']), R.Fixed(g['pair/phase'])), R.Fixed(g['pair/mix'])),
+                   R.Fixed(g['pair/cutoff']))
+    ref = g['pair/pre_gain_Triangle_hp']
+    assert same(R.render_stream(pre, 0, 256, 3, ref.shape[1]), ref)
+
+
 def test_blockloc_table(golden):
     for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
         assert R.before(int(pos), int(n), 100) == (bp, bf)
