@@ -571,22 +571,22 @@ def main():
 
     by_batch = None
     if world == 1 and not args.single_mode and not args.materialised:
-        # the same schedule at smaller batches (BASELINE.md's throughput mode is K = 256), clocks already settled
+        # the same schedule at other batch lengths (BASELINE.md's throughput mode is K = 256), clocks already settled
         from signals_amd.engine import BatchRenderer
         by_batch = {}
-        for k in (256, 1024):
+        for k in (256, 1024, 8192, 16384):                  # (the longer ones: two and four waves per SIMD instead of one)
             if k == K:
                 continue
             r = BatchRenderer(build_graph(params, 0, V), 2, RATE)
-            pos = 0
+            pos, reps = 0, max(20, 200 * 1024 // max(k, 1024))
             for _ in range(10):
                 r.render(pos, N, k); pos += N * k
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(200):
+            for _ in range(reps):
                 r.render(pos, N, k); pos += N * k
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 200
+            dt = (time.perf_counter() - t0) / reps
             by_batch[str(k)] = {'Msamples_per_s': V * N * k / dt / 1e6, 'ms_per_step': dt * 1e3}
 
     latency = None
