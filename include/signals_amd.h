@@ -275,12 +275,13 @@ int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
 /* A block-rate control subgraph as one launch.  The reference reads a control port once per block, at the block's position
  * (BoundPort.forward_at_block_rate, chain/__init__.py:305-306); an LFO sweep or a tremolo is an oscillator evaluated at one
  * frame per block (Osc._eval, osc.py:26-62) combined by element-wise nodes (fx.py:35-60).  `program` (device memory, n_ins <=
- * SIG_CTL_MAX_INS) is that subgraph in evaluation order over registers dst < min(n_ins, SIG_CTL_MAX_REGS); thread (b, v) runs it for
+ * SIG_CTL_MAX_INS = SIG_CTL_MAX_REGS: one register per instruction, the register file is sized by n_ins; a longer program is refused with
+ * hipErrorInvalidValue) is that subgraph in evaluation order over registers dst < n_ins; thread (b, v) runs it for
  * block b (frame position + b * step) at column v < cols and writes register outs[k].reg to outs[k].out[b * outs[k].cols + v]
  * for v < outs[k].cols.  A register index of -1 reads 0.  Same expressions as sig_osc_bank (f64 store) and sig_elementwise,
  * so the same bits as the node-by-node evaluation. */
 enum { SIG_CTL_ROW = 0, SIG_CTL_OSC = 1, SIG_CTL_GAIN = 2, SIG_CTL_MIX = 3, SIG_CTL_RINGMOD = 4, SIG_CTL_AMP = 5 };
-enum { SIG_CTL_MAX_REGS = 48, SIG_CTL_MAX_INS = 64 };
+enum { SIG_CTL_MAX_REGS = 48, SIG_CTL_MAX_INS = 48 };
 typedef struct {
     int32_t op;              /* SIG_CTL_* */
     int32_t kind;            /* OSC: SIG_OSC_* */
@@ -300,9 +301,15 @@ int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nb
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
  * -- Osc._eval (chain/osc.py:26-62), CritFilter._filter (chain/fx.py:85-121), Gain._eval (chain/fx.py:49-52) and the
  * build-defined MixMatrix, i.e. the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going
- * through HBM: every 32 rows of a 64-voice group are staged as float32 in LDS and multiplied on the matrix cores
- * (exact-f32 MFMA, same k order as sig_mix_matrix, so the result equals sig_mix_matrix over sig_fused_osc_biquad's
- * output bit for bit).  voices % 64 == 0; matrix (64, 64) float32 row-major on the device. */
+ * through HBM: every 32 rows of a 64-voice group are staged as float32 in LDS and multiplied on the matrix cores.  The default
+ * sink contracts each float32 operand as the exact sum of three bfloat16 (six v_mfma_f32_32x32x16_bf16 products per k-block,
+ * float32 accumulators, the three cross terms below 2^-26 of a product dropped; sig_mix_tile.h): WITHIN A FEW float32 ULP of
+ * sig_mix_matrix over sig_fused_osc_biquad's output (measured 4-7 ulp of the rows' scale between the two, each 2-5 ulp from
+ * the f64 product), not bit for bit.  sig_fused_set_tuning(closed_form = 3) selects v_mfma_f32_32x32x2_f32 (the instruction
+ * of sig_mix_matrix) instead.  Non-finite rows: the split forms x - bf16(x), so an Inf sample becomes NaN in the mixed row where
+ * the float32 instruction keeps Inf (either way the row is unusable and a rejected design also sets the status bit); residual
+ * words below bfloat16's range (|x| < ~1e-33 after two splits) flush to zero, an absolute error below 1e-35.
+ * voices % 64 == 0; matrix (64, 64) float32 row-major on the device. */
 int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t position,
                              int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                              const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,

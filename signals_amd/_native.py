@@ -52,7 +52,7 @@ class CtlOut(ctypes.Structure):
 
 
 CTL_OPS = {'Row': 0, 'Osc': 1, 'Gain': 2, 'Mix': 3, 'RingMod': 4, 'Amp': 5}
-CTL_MAX_REGS, CTL_MAX_INS = 48, 64
+CTL_MAX_REGS, CTL_MAX_INS = 48, 48
 
 
 class Operand(ctypes.Structure):

@@ -1,8 +1,7 @@
 """`signals.chain.discovery` (reference src/signals/chain/discovery.py:19-140): `load_signal` resolves the qualified
 class names `.sigs` patches and scripts use, with the reference's error types; `Library.scan` lists the node classes
 of this package and of user plugin directories -- any concrete `Signal` subclass defined in a scanned module is a
-node (:71-93); `Rack` enumerates the audio devices -- here the one null device of `signals_amd.chain.dev` (PortAudio is
-out of scope), with the reference's lookups and errors (:96-126)."""
+node (:71-93).  The device `Rack` (:96-126) is not provided: audio devices are out of scope."""
 import abc
 import importlib
 import importlib.util
@@ -56,67 +55,6 @@ def load_signal(qualname: str) -> typing.Type[signals_amd.chain.Signal]:
     if not is_concrete_subclass(cls, signals_amd.chain.Signal):
         raise InvalidObject(qualname, cls)
     return cls
-
-
-class BadDevice(DiscoveryError):
-    pass
-
-
-class BadDeviceName(BadDevice):
-
-    def __init__(self, name):
-        super().__init__(f'There is no device named {name!r}')
-
-
-class BadDeviceChannels(BadDevice):
-    pass
-
-
-class NotASource(BadDeviceChannels):
-
-    def __init__(self, name):
-        super().__init__(f'Device {name!r} does not support input')
-
-
-class NotASink(BadDeviceChannels):
-
-    def __init__(self, name):
-        super().__init__(f'Device {name!r} does not support output')
-
-
-class Rack:
-    """the audio devices of the machine: the null sink `default` (rendered blocks are dropped or handed to `on_block`)"""
-
-    def __init__(self):
-        self.devices = []
-
-    def scan(self) -> None:
-        from signals_amd.chain import dev
-        self.devices[:] = [dev.DeviceInfo(name='default', index=0, max_input_channels=0, max_output_channels=2)]
-
-    def get_device(self, name: str):
-        found = [d for d in self.devices if d.name == name]
-        if len(found) != 1:
-            raise BadDeviceName(name)
-        return found[0]
-
-    def get_source(self, name: str):
-        device = self.get_device(name)
-        if not device.is_source:
-            raise NotASource(name)
-        return device
-
-    def get_sink(self, name: str):
-        device = self.get_device(name)
-        if not device.is_sink:
-            raise NotASink(name)
-        return device
-
-    def sources(self) -> list:
-        return sorted(d for d in self.devices if d.is_source)
-
-    def sinks(self) -> list:
-        return sorted(d for d in self.devices if d.is_sink)
 
 
 class Library:

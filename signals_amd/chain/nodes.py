@@ -332,6 +332,8 @@ def concatenate(blocks: typing.Sequence[torch.Tensor]) -> torch.Tensor:
     if len(widths) > 1:
         raise ValueError('all the input array dimensions except for the concatenation axis must match exactly, '
                          f'got channel counts {sorted(widths)}')
+    if any(isinstance(b, np.ndarray) for b in blocks):      # a HOST_ARRAYS receiver (a reference-style plugin): its ports hand it numpy
+        return np.concatenate([np.asarray(b) for b in blocks])
     dtypes = {b.dtype for b in blocks}
     if len(dtypes) > 1:
         blocks = [b.to(CTRL_DTYPE) for b in blocks]

@@ -111,8 +111,10 @@ extern "C" int sig_control_program(int32_t rate, int64_t position, int32_t step,
     SIG_CHECK_ARG(rate > 0 && position >= 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0 && front_position >= -1);
     SIG_CHECK_ARG((program || n_ins == 0) && (outs || n_outs == 0) && n_ins <= SIG_CTL_MAX_INS);
     if ((nblocks == 0 && front_position < 0) || n_outs == 0) return 0;
-    int n_regs = 1;                                                            // (the program is in host-visible device memory only: the caller says how many)
-    n_regs = n_ins < SIG_CTL_MAX_REGS ? (n_ins > 0 ? n_ins : 1) : SIG_CTL_MAX_REGS;   // registers are assigned in instruction order (dst < n_ins)
+    // one register per instruction (dst < n_ins): the program lives in device memory, so register indices cannot be checked
+    // here -- the LDS register file is sized by n_ins, and n_ins <= SIG_CTL_MAX_INS == SIG_CTL_MAX_REGS was checked above
+    static_assert(SIG_CTL_MAX_INS <= SIG_CTL_MAX_REGS, "the register file is sized by the instruction count");
+    const int n_regs = n_ins > 0 ? n_ins : 1;
     control_program_kernel<<<(unsigned)(nblocks + (front_position >= 0 ? 1 : 0)), kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols, front_position,
                                                                                           program, n_ins, outs, n_outs);
     return sig_launch_status();

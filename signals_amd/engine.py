@@ -176,8 +176,9 @@ class BatchRenderer:
         self._ctl_programs: dict = {}                      # compiled block-rate control programs, by (port sources, K)
         self._tremolo_order = None                         # (key, held tensors, index, ordered constant rows, ordered pan) of a tremolo-only Sine voice
         self._prev_block_frames: int | None = None         # N of the previous render (where a fused cascade's history block starts)
-        self._virtual_history = False                      # the previous batch kept its filter history implicit (no tails needed)
-        self._cascade_stream = False                       # ... and this batch continues it
+        self._virtual_history: set = set()                 # bus nodes whose launch of THIS batch kept its filter history implicit (no tails)
+        self._cascade_stream: set = set()                  # ... of the previous batch, when this one continues it
+        self._tails_rebuilt = False                        # the previous block was re-rendered per node for this batch's tails
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -202,11 +203,12 @@ class BatchRenderer:
                 self._stream_end = position + block_frames * nblocks
                 return launch(position)
             self._replay = None
-        continuing = self._stream_end == position and (bool(self._tails) or self._virtual_history)
+        continuing = self._stream_end == position and (bool(self._tails) or bool(self._virtual_history))
         if not continuing:
             self._tails.clear()
-        self._cascade_stream = continuing and self._virtual_history    # the previous batch ran the fused cascade
-        self._virtual_history = False                      # set again by a launch that keeps its history implicit (fused cascade)
+        self._cascade_stream = self._virtual_history if continuing else set()    # buses the previous batch ran through the fused cascade
+        self._virtual_history = set()                      # filled again by launches that keep their history implicit (fused cascade)
+        self._tails_rebuilt = False
         batch = _Batch(self, position, block_frames, nblocks, continuing)
         out = batch.buffer(self.node, self.channels, 0)
         for node, buf in batch.impure_outputs():
@@ -216,9 +218,31 @@ class BatchRenderer:
         self._prev_block_frames = block_frames
         return out
 
+    def _rebuild_tails(self, position: int) -> None:
+        """The previous batch ran (part of) the graph through the fused cascade, which leaves no tails, and this one needs
+        the per-node schedule for it (a block size the kernel does not take, a node that gained a reader, `fuse_cascade`
+        switched off ...): render the previous block [position - prevN, position) per node, as its own block -- an inner
+        filter then cold-starts min(100, .) rows in front of it, exactly where the reference cold-started the block it keeps
+        cached (chain/__init__.py:431-442, fx.py:93-94) -- and keep the last 100 rows of every request-dependent node."""
+        self._tails_rebuilt = True
+        prev = self._prev_block_frames
+        if not prev or position - prev < 0:
+            return
+        keep_fuse, keep_virtual, keep_replay = self.fuse_cascade, self._virtual_history, self._replay
+        self.fuse_cascade = False
+        try:
+            sub = _Batch(self, position - prev, prev, 1, False)
+            sub.buffer(self.node, self.channels, 0)
+            for node, buf in sub.impure_outputs():
+                if node not in self._tails:
+                    keep = min(CONTEXT, buf.shape[0])
+                    self._tails[node] = (position, buf[buf.shape[0] - keep:].clone())
+        finally:
+            self.fuse_cascade, self._virtual_history, self._replay = keep_fuse, keep_virtual, keep_replay
+
     def reset(self) -> None:
         self._tails.clear()
-        self._virtual_history = False
+        self._virtual_history = set()
         self._stream_end = None
         self._replay = None
         self._captured = None
@@ -325,6 +349,8 @@ class _ControlProgram:
             if src is None or not src.get_state().enabled:
                 self.results.append(Emitter.empty_result())
             elif isinstance(src, fixed.Fixed):
+                if src.resident().shape[0] != 1:
+                    raise NotBatchable('multi-row Fixed on a control port')
                 self.results.append(None)                   # its resident row, fetched per run
             else:
                 reg, cols = self._emit(src)
@@ -400,6 +426,8 @@ class _ControlProgram:
                           lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
                                                           self.outs_t, self.n_outs, front_position), units=self.K * self.cols)
         rows = [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
+        if any(t.shape[0] not in (1, self.K) or (r is None and t.shape[0] != 1) for t, r in zip(rows, self.results)):
+            raise NotBatchable('multi-row Fixed on a control port')             # (edited since the program was compiled)
         if front_position < 0:
             return rows
         return rows, [self.fronts.get(i, rows[i]) for i in range(len(rows))]
@@ -739,7 +767,7 @@ class _Batch:
             # the block in front of this batch: the kernel re-walks it from where the reference cold-started it.  Only if
             # the previous render kept its history implicit as well (a per-node batch left tails of rounded float32 rows)
             # and that block covers the outer filter's context
-            if not o._cascade_stream or not o._prev_block_frames or o._prev_block_frames < min(CONTEXT, self.pos):
+            if node not in o._cascade_stream or not o._prev_block_frames or o._prev_block_frames < min(CONTEXT, self.pos):
                 return None
             history = self.pos - o._prev_block_frames
         else:
@@ -750,7 +778,7 @@ class _Batch:
             o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
         status = o._status_word(f2)                                            # one word for the launch: both designs report here
         kind, t1, t2 = src.kind(), str(f1.type()), str(f2.type())
-        o._virtual_history = True
+        o._virtual_history.add(node)
         out = o._launch(f'fused_cascade_bus[{kind},{t1},{t2}{",env" if ctl else ""}]',
                         lambda: _native.fused_cascade_bus(kind, t1, t2, self.rate, self.pos, history, N, self.K, CONTEXT, voices,
                                                           hertz, phase, cut1, cut2, None, ctl, gains, result,
@@ -935,6 +963,9 @@ class _Batch:
             return
         o, pos = self.owner, self.pos
         tail = o._tails.get(node) if self.continuing else None
+        if tail is None and self.continuing and o._cascade_stream and not o._tails_rebuilt:
+            o._rebuild_tails(pos)                                              # (the previous batch kept this history implicit)
+            tail = o._tails.get(node)
         if tail is not None and tail[0] == pos and tail[1].shape[0] >= hist and tail[1].shape[1] >= channels:
             result[:hist].copy_(tail[1][tail[1].shape[0] - hist:, :channels])
         else:

@@ -49,6 +49,13 @@ def test_argument_errors_do_not_reach_the_device(lib):
     lib.sig_mix_matrix.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     assert lib.sig_mix_matrix(32, 100, 16, 100, 16, 16, 100, None) == inv                        # voices % 64
+    # a control program longer than its register file (one register per instruction, SIG_CTL_MAX_INS == SIG_CTL_MAX_REGS == 48)
+    lib.sig_control_program.restype = ctypes.c_int
+    lib.sig_control_program.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 16, 49, 16, 1, None) == inv
+    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 16, 64, 16, 1, None) == inv
+    assert lib.sig_control_program(48000, 0, 256, 0, 8, -1, 16, 48, 16, 1, None) == 0             # accepted; no blocks: no launch
 
 
 def test_fused_geometry_needs_no_device():

@@ -388,6 +388,37 @@ def test_numpy_plugin_nodes_interoperate_at_the_ports():
         p.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(4, 1)))
 
 
+def test_numpy_plugin_filter_reads_its_input_with_context():
+    """a reference-style effect that pulls `forward_with_context` (the CritFilter pattern, fx.py:93-94) gets ONE float64 numpy
+    window [<=100 before | block | 100 after] (chain/__init__.py:308-315)"""
+
+    class NumpyDiff(chain.ImplicitChannels):
+        input = port('input')
+        HOST_ARRAYS = True
+
+        @classmethod
+        def flags(cls):
+            return SignalFlags.EFFECT
+
+        def _eval(self, request):
+            w = self.input.forward_with_context(request, 100)
+            assert isinstance(w, np.ndarray) and w.dtype == np.float64
+            n, c = request.loc.shape.frames, min(100, request.loc.position)
+            assert w.shape[0] == c + n + 100
+            return np.diff(w, axis=0, prepend=0.0)[c:c + n]
+
+    src = NumpyRamp(); src.get_state().channels = 2
+    fx_ = NumpyDiff(); fx_.input = src
+    p = Probe(); p.input = fx_
+    for pos in (0, 37, 4800):
+        got = p.input.request(chain.BlockLoc(position=pos, rate=48000, shape=chain.Shape(8, 2))).numpy()
+        ramp = lambda a, b: (np.arange(a, b).reshape(-1, 1) / 48000) * np.array([[1, 2]])
+        lo = pos - min(100, pos)
+        window = np.concatenate([ramp(lo, pos), ramp(pos, pos + 8), ramp(pos + 8, pos + 108)]).astype(np.float32).astype(np.float64)
+        want = np.diff(window, axis=0, prepend=0.0)[pos - lo:pos - lo + 8]
+        assert np.array_equal(got, want.astype(np.float32)), pos
+
+
 def test_install_as_signals_aliases_every_chain_module_scripts_import():
     import importlib
     import signals_amd
@@ -448,43 +479,22 @@ def test_library_scan_finds_plugin_nodes(tmp_path):
     assert np.array_equal(p.input.request(chain.BlockLoc(position=0, rate=48000, shape=chain.Shape(3, 2))).numpy(), np.ones((3, 2)))
 
 
-def test_null_sink_device_runs_the_callback_loop_like_portaudio_would():
-    """signals.chain.dev.SinkDevice around a null device (reference dev.py:90-179): open / start / stop / close life cycle,
-    one block per callback at frame_position, an exception in the graph stops the stream; Rack lists the device"""
-    import time
-    from signals_amd.chain import dev, discovery
-    rack = discovery.Rack()
-    rack.scan()
-    assert [d.name for d in rack.sinks()] == ['default'] and rack.sources() == []
-    with pytest.raises(discovery.BadDeviceName):
-        rack.get_sink('nope')
-    with pytest.raises(discovery.NotASource):
-        rack.get_source('default')
-    sink = dev.SinkDevice(rack.get_sink('default'), blocksize=64, realtime=False)
-    assert not sink.is_open and not sink.is_active and sink.flags() & SignalFlags.SINK_DEVICE
-    with pytest.raises(dev.BadPlaybackState):
-        sink.stop()
-    with pytest.raises(ValueError):
-        sink.set_state(sink.State(channels=5))             # the device has two channels
+def test_sink_device_name_is_the_headless_block_driver():
+    """audio devices are out of scope: `signals.chain.dev.SinkDevice` is the headless BlockDriver under the
+    name graph scripts import -- callers pull blocks themselves; an exception in the graph marks the stream inactive
+    (reference dev.py:174-176)"""
+    from signals_amd.chain import dev
+    from signals_amd.chain.driver import BlockDriver
+    sink = dev.SinkDevice(blocksize=64)
+    assert isinstance(sink, BlockDriver) and sink.flags() & SignalFlags.SINK_DEVICE and sink.port_names() == ['input']
     src = fixed.Fixed(); src.get_state().value = np.array([[0.25, -0.5]])
     sink.input = src
     sink.set_state(sink.State(channels=2))
-    played = []
-    sink.on_block = played.append
-    sink.start()
-    assert sink.is_open
-    deadline = time.time() + 10
-    while sink.tell() < 5 and time.time() < deadline:
-        time.sleep(0.001)
-    sink.stop()
-    assert not sink.is_active and sink.is_open and sink.tell() >= 5 and sink.frame_position == 64 * sink.tell()
-    assert len(played) == sink.tell() and played[0].shape == (64, 2) and np.all(played[0] == np.array([[0.25, -0.5]], dtype=np.float32))
+    blocks = [sink.pull(eager=True) for _ in range(3)]
+    assert sink.tell() == 3 and sink.frame_position == 192
+    assert blocks[0].shape == (64, 2) and np.all(blocks[0] == np.array([[0.25, -0.5]], dtype=np.float32))
     sink.seek(100)
     assert sink.tell() == 100
-    with pytest.raises(dev.BadPlaybackState):
-        sink.open()
-    sink.close()
-    assert not sink.is_open
 
     class Broken(chain.ExplicitChannelsEmitter):
         @classmethod
@@ -493,16 +503,13 @@ def test_null_sink_device_runs_the_callback_loop_like_portaudio_would():
 
         def _eval(self, request):
             raise RuntimeError('boom')
-    bad = dev.SinkDevice(blocksize=32, realtime=False)
-    bad.log = lambda msg: None
+    bad = dev.SinkDevice(blocksize=32)
     bad.input = Broken()
-    bad.start()
-    deadline = time.time() + 10
-    while bad.is_active and time.time() < deadline:
-        time.sleep(0.001)
-    assert not bad.is_active and bad.tell() == 0           # dev.py:174-176: the exception ended the stream
+    with pytest.raises(RuntimeError):
+        bad.pull(eager=True)
+    assert not bad.is_active and bad.tell() == 0
     bad.destroy()
-    assert not bad.is_open and not bad.input
+    assert not bad.input
 
 
 def test_reference_script_imports_resolve():
@@ -513,10 +520,8 @@ def test_reference_script_imports_resolve():
         signals_amd.install_as_signals()
         for name in ('signals.chain.dev', 'signals.chain.discovery', 'signals.chain.fixed', 'signals.chain.osc', 'signals.map.control'):
             importlib.import_module(name)
-        import signals.chain.discovery
-        rack = signals.chain.discovery.Rack(); rack.scan()
         import signals.chain.dev
-        sink = signals.chain.dev.SinkDevice(rack.get_sink('default'))
+        sink = signals.chain.dev.SinkDevice()
         sine = signals.chain.osc.Sine(); sink.input = sine
         assert sink.input.sig is sine
     finally:

@@ -218,7 +218,7 @@ def test_mix_matrix_mfma_layout_and_values():
         xt = torch.from_numpy(x).cuda()
         out = _native.mix_matrix(xt, torch.from_numpy(M.astype(np.float32)).cuda(), torch.empty_like(xt)).cpu().numpy()
         ref = R.mix_matrix(x.astype(np.float64), M.astype(np.float32).astype(np.float64))
-        assert maxerr(out, ref) < 2e-6, (rows, V)        # 64-term f32 fmaf chain, |x*m| sum ~ 6
+        assert maxerr(out, ref) < 1e-6 * max(1.0, float(np.abs(ref).max())), (rows, V)        # 64-term float32 accumulation, full scale ~4
     eye = np.zeros((64, 64), dtype=np.float32); eye[np.arange(64), np.arange(64)] = 1
     asym = (np.arange(64)[:, None] * 64 + np.arange(64)[None, :]).astype(np.float32)      # exact integers
     out = _native.mix_matrix(torch.from_numpy(eye).cuda(), torch.from_numpy(asym).cuda(),
@@ -267,7 +267,7 @@ def test_c5_config_vs_oracle():
     got = batched(build(), 0, N, K, V)
     lp = R.render_stream(R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), R.Fixed(cut)), 0, N, K, V)
     ref = R.mix_matrix(lp, M.astype(np.float32).astype(np.float64))
-    assert maxerr(got, f32(ref)) < 2e-6
+    assert maxerr(got, f32(ref)) < min(2e-6, 1e-6 * float(np.abs(ref).max()))
     assert np.array_equal(got, stream(build(), 0, N, K, V))
     # engine default: the chain and the matrix in one launch (sig_fused_osc_biquad_mix), mid-stream too
     from signals_amd.engine import BatchRenderer, KernelTimer
@@ -277,7 +277,8 @@ def test_c5_config_vs_oracle():
     torch.cuda.synchronize()
     assert set(timer.summary()) == {'fused_osc_biquad_mix[Sine,lp]'}, set(timer.summary())
     lp = R.render_stream(R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), R.Fixed(cut)), 0, N, K + 3, V)
-    assert maxerr(fused, f32(R.mix_matrix(lp, M.astype(np.float32).astype(np.float64)))) < 2e-6
+    ref = R.mix_matrix(lp, M.astype(np.float32).astype(np.float64))
+    assert maxerr(fused, f32(ref)) < min(2e-6, 1e-6 * float(np.abs(ref).max()))
 
 
 def test_fused_voice_chain_vs_golden_and_unfused(golden):
@@ -641,7 +642,7 @@ def test_ringmod_with_adsr_in_one_pass():
                          R.Fixed(p['cut2']))
         ref = R.render_stream(chain, 0, N, K, V)
         want = ref @ pan.T if stereo else (ref * (p['cut1'] / 8000.0)).sum(axis=1, keepdims=True)
-        assert maxerr(got, f32(want)) < 2e-6, stereo
+        assert maxerr(got, f32(want)) < min(2e-6, 1e-6 * max(1.0, float(np.abs(want).max()))), stereo
 
     # the filter has a second consumer: its rows must exist un-enveloped, the envelope is applied in one pass
     bus, p = c3_graph(V)

@@ -172,9 +172,11 @@ def test_one_hour_stream_stays_finite_and_position_pure(params):
 
 
 def test_config3_full_size_schedules_agree_and_spot_check():
-    """BASELINE config 3 at its own size (1024 voices, 1024-frame blocks): the engine's fused schedule (fused
-    saw+filter, then filter + envelope + bus in one pass) against the one-kernel-per-node schedule over a continued
-    stream, and 6 sampled voices of the enveloped cascade against the oracle"""
+    """BASELINE config 3 at its own size (1024 voices, 1024-frame blocks): the engine's default schedule (the whole voice in
+    one launch, sig_fused_cascade_bus) against the one-kernel-per-node schedule over a continued stream -- two GPU
+    schedules, each within 1e-6 of full scale of the f64 reference, so they agree to twice that -- and 6 sampled voices of
+    the enveloped cascade WITHOUT the bus (fused saw + filter, then filter x envelope) against the oracle.  The bus kernel
+    itself against the oracle at this size, deep in the stream: tests/test_gpu_parity_holes.py"""
     import sys, pathlib
     sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / 'tools'))
     import measure_configs as mc
@@ -188,7 +190,8 @@ def test_config3_full_size_schedules_agree_and_spot_check():
         r = BatchRenderer(bus, 1, RATE, fuse=fuse)
         outs[fuse] = torch.cat([r.render(0, Nc, Kc), r.render(Nc * Kc, Nc, 4)]).double()       # a second batch continues
     assert bool(torch.isfinite(outs[True]).all()) and float(outs[True].abs().max()) > 1.0
-    assert float((outs[True] - outs[False]).abs().max()) < 2e-5          # bus of 1024 voices of O(1): ~1e-7 relative
+    full = float(outs[False].abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) < 2e-6 * full    # full scale ~8.7: two schedules, 1e-6 of it each
     # per-voice spot check: rebuild the graph's parameters exactly as measure_configs.c3 draws them
     rng = np.random.default_rng(0)
     hz, ph = rng.uniform(55, 1760, (1, Vc)), rng.uniform(0, 1, (1, Vc))
@@ -218,8 +221,9 @@ def test_config5_full_size_fused_equals_two_launches():
         mm, channels, n, k, _ = mc.c5(4096, 64)
         outs[fuse] = BatchRenderer(mm, channels, RATE, fuse=fuse).render(0, n, k)
     assert outs[True].shape == (256 * 64, 4096) and bool(torch.isfinite(outs[True]).all())
-    assert float((outs[True].double() - outs[False].double()).abs().max()) < 2e-6
-    assert float(outs[True].abs().max()) > 0.5
+    full = float(outs[False].abs().max())
+    assert float((outs[True].double() - outs[False].double()).abs().max()) < min(2e-6, 1e-6 * full)     # (vs the oracle: test_gpu_parity_holes.py)
+    assert full > 0.5
 
 
 def test_bench_geometry_vs_oracle(params):

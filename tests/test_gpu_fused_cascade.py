@@ -84,7 +84,7 @@ def test_c3_graph_is_one_launch_and_matches_the_oracle():
     # the per-node schedule and the eager pull path (bit-identical to each other) agree to their own float32 roundings
     from signals_amd.engine import BatchRenderer
     plain = BatchRenderer(graph(p), 1, RATE, fuse=False).render(0, N, K).cpu().numpy()
-    assert maxerr(got, plain) < 2e-6 * scale
+    assert maxerr(plain, f32(ref)) < 1e-6 * scale                    # (each schedule against the oracle, not against each other)
 
 
 def test_continuing_stream_equals_one_long_batch_and_the_oracle():
@@ -122,7 +122,7 @@ def test_waveforms_filter_types_and_bus_widths(kind, t1, t2):
             got = fused(graph(p, kind, t1, t2, env=env, gain=gain, pan=pan), C).render(0, N, K).cpu().numpy()
             ref = oracle_stream(p, 0, N, K, V, kind=kind, t1=short[t1], t2=short[t2], env=env, gain=gain, pan=pan)
             scale = max(1.0, np.abs(ref).max())
-            assert got.shape == (N * K, C) and maxerr(got, f32(ref)) < 1.5e-6 * scale, (kind, C, env)
+            assert got.shape == (N * K, C) and maxerr(got, f32(ref)) < 1e-6 * scale, (kind, C, env)
 
 
 def test_golden_cascades_of_the_reference(golden):
@@ -163,7 +163,7 @@ def test_every_launch_geometry():
                     assert _native.fused_cascade_geometry(V, K) == (vpt, span)
                     r = fused(graph(p, pan=p['pan']), 2)
                     got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(K * N, N, 3).cpu().numpy()])
-                    assert maxerr(got, f32(ref)) < 1.5e-6 * max(1.0, np.abs(ref).max()), (V, N, K, vpt, span)
+                    assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), (V, N, K, vpt, span)
     finally:
         _native.set_fused_cascade_tuning()
     assert _native.fused_cascade_geometry(1024, 1024) == (4, 4) and _native.fused_cascade_geometry(1024, 256) == (2, 2)
@@ -257,7 +257,7 @@ def test_block_sizes_the_cascade_kernel_does_not_take_fall_back_to_the_older_sch
         names = set(timer.summary())
         assert not any(n.startswith('fused_cascade_bus') for n in names) and any(n.startswith('biquad_bus') for n in names), names
         ref = oracle_stream(p, 0, N, K, V)
-        assert maxerr(got, f32(ref)) < 2e-6 * max(1.0, np.abs(ref).max()), N
+        assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), N
 
 
 def test_a_stream_may_switch_between_the_per_node_schedule_and_the_cascade_kernel():
@@ -281,7 +281,45 @@ def test_a_stream_may_switch_between_the_per_node_schedule_and_the_cascade_kerne
     c = r.render(4 * N, N, 2).cpu().numpy()                   # a FRESH start mid-stream: the cascade kernel, fresh-graph history
     torch.cuda.synchronize()
     assert any(n.startswith('fused_cascade_bus') for n in timer.summary())
-    assert maxerr(np.concatenate([a, b]), f32(ref[:4 * N])) < 2e-6 * scale
+    assert maxerr(np.concatenate([a, b]), f32(ref[:4 * N])) < 1e-6 * scale
     from oracle import chain_ref as R
     node, _ = oracle(p)
-    assert maxerr(c, f32(R.sum_bus(R.render_stream(node, 4 * N, N, 2, V)))) < 2e-6 * scale
+    assert maxerr(c, f32(R.sum_bus(R.render_stream(node, 4 * N, N, 2, V)))) < 1e-6 * scale
+
+
+def test_a_cascade_batch_followed_by_a_batch_the_kernel_does_not_take():
+    """the cascade kernel leaves no tails; when the NEXT contiguous batch needs the per-node schedule (a block size that is
+    not a whole number of row groups, `fuse_cascade` switched off) the engine first re-renders the previous block per node
+    -- the inner filter cold-started where the reference cold-started the block it keeps cached -- so the outer filter's
+    context is that block's last 100 rows, not a fresh block cold-started at p - 200.  Slow inner filters: the difference
+    between the two is far above the bar."""
+    from signals_amd.engine import KernelTimer
+    V, N = 24, 256
+    p = params(V, 43)
+    p['cut1'][0, :8] = np.linspace(20.0, 120.0, 8)
+    from oracle import chain_ref as R
+    node, _ = oracle(p)
+    ref = R.sum_bus(np.concatenate([R.render_stream(node, 0, N, 3, V), R.render_stream(node, 3 * N, 250, 2, V)]))
+    scale = max(1.0, np.abs(ref).max())
+    timer = KernelTimer()
+    r = fused(graph(p), 1, timer)
+    a = r.render(0, N, 3).cpu().numpy()                       # the cascade kernel
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'fused_cascade_bus[Sawtooth,lp,lp,env]'}
+    timer.reset()
+    b = r.render(3 * N, 250, 2).cpu().numpy()                 # 250 frames: not a whole number of 16-row groups -> per node
+    torch.cuda.synchronize()
+    assert not any(n.startswith('fused_cascade_bus') for n in timer.summary())
+    assert maxerr(np.concatenate([a, b]), f32(ref)) < 1e-6 * scale
+    fresh = fused(graph(p), 1).render(3 * N, 250, 2).cpu().numpy()
+    assert maxerr(fresh, b) > 1e-5 * scale                    # ... which a fresh start at 3 N does NOT render
+    # the same with the kernel switched off mid-stream, and back on: every batch the oracle's sequential stream
+    ref2 = R.sum_bus(R.render_stream(oracle(p)[0], 0, N, 7, V))
+    r2 = fused(graph(p), 1)
+    parts = [r2.render(0, N, 2)]
+    r2.fuse_cascade = False
+    parts.append(r2.render(2 * N, N, 2))
+    r2.fuse_cascade = True
+    parts.append(r2.render(4 * N, N, 3))                      # continues per-node tails: stays per node
+    got = torch.cat(parts).cpu().numpy()
+    assert maxerr(got, f32(ref2)) < 1e-6 * max(1.0, np.abs(ref2).max())

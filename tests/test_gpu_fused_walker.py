@@ -36,6 +36,13 @@ def dev(a):
     return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device='cuda')
 
 
+def bar(ref, cap=None):
+    """BASELINE's bar for a bus: 1e-6 of its full scale (never below 1: a float32 bus of |x| < 1 is compared absolutely),
+    and never looser than `cap` where an absolute tolerance was already met"""
+    tol = 1e-6 * max(1.0, float(np.abs(ref).max()))
+    return tol if cap is None else min(tol, cap)
+
+
 def params(V, seed, hz_hi=1760.0):
     rng = np.random.default_rng(seed)
     th = rng.uniform(0, np.pi / 2, V)
@@ -89,7 +96,7 @@ def test_every_geometry_matches_the_oracle(kind):
         assert np.isfinite(got).all(), (vpt, span)
         assert maxerr(got, f32(ref)) < 2e-7, (kind, vpt, span)
         bus = run_bus(kind, btype, p, pos, N, K)
-        assert maxerr(bus, f32(ref_bus)) < 2e-6, (kind, vpt, span)          # sums of 200 voices of O(1)
+        assert maxerr(bus, f32(ref_bus)) < bar(ref_bus, 2e-6), (kind, vpt, span)          # sums of 200 voices of O(1)
 
 
 def test_geometries_agree_with_each_other_to_rounding():
@@ -138,7 +145,7 @@ def test_sine_falls_back_to_the_exact_phase():
     for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 4)]:
         geometry(vpt, span)
         assert maxerr(run_chain('Sine', 'hp', p, 512, N, K), f32(ref)) < 3e-7, (vpt, span)
-        assert maxerr(run_bus('Sine', 'hp', p, 512, N, K), f32(ref @ p['pan'].T)) < 2e-6, (vpt, span)
+        assert maxerr(run_bus('Sine', 'hp', p, 512, N, K), f32(ref @ p['pan'].T)) < bar(ref @ p['pan'].T, 2e-6), (vpt, span)
 
 
 def test_low_and_negative_frequencies_and_long_spans():
@@ -160,8 +167,8 @@ def test_mono_and_quad_bus_and_missing_gain():
     p['pan'] = rng.uniform(-1, 1, (4, V))
     ref = oracle_chain('Triangle', 'lp', p, 0, N, K)
     geometry(2, 2)
-    assert maxerr(run_bus('Triangle', 'lp', p, 0, N, K, C=4), f32(ref @ p['pan'].T)) < 2e-6
-    assert maxerr(run_bus('Triangle', 'lp', p, 0, N, K, C=1), f32(ref.sum(axis=1, keepdims=True))) < 2e-6
+    assert maxerr(run_bus('Triangle', 'lp', p, 0, N, K, C=4), f32(ref @ p['pan'].T)) < bar(ref @ p['pan'].T, 2e-6)
+    assert maxerr(run_bus('Triangle', 'lp', p, 0, N, K, C=1), f32(ref.sum(axis=1, keepdims=True))) < bar(ref.sum(axis=1, keepdims=True), 2e-6)
     nogain = dict(p, gain=np.ones((1, V)))
     assert maxerr(run_chain('Triangle', 'lp', p, 0, N, K, gain=False), f32(oracle_chain('Triangle', 'lp', nogain, 0, N, K))) < 2e-7
 
@@ -199,7 +206,7 @@ def test_closed_form_sine_kernel_matches_the_walker_and_the_oracle(btype, pos):
         steady = run_bus('Sine', btype, p, pos, N, K)
         assert np.isfinite(steady).all()
         assert maxerr(steady, walker) < 5e-7, (vpt, span)                # sums of 200 voices, up to +-2: two float32 ulps
-        assert maxerr(steady, f32(ref_bus)) < 2e-6, (vpt, span)
+        assert maxerr(steady, f32(ref_bus)) < bar(ref_bus, 2e-6), (vpt, span)
 
 
 def test_closed_form_kernel_leaves_unqualified_waves_to_the_walker():
@@ -213,11 +220,11 @@ def test_closed_form_kernel_leaves_unqualified_waves_to_the_walker():
     ref_bus = oracle_chain('Sine', 'lp', p, 512, N, K) @ p['pan'].T
     for vpt, span in [(1, 1), (1, 4), (2, 2), (4, 8), (8, 2), (8, 1)]:
         geometry(vpt, span, steady=1)
-        assert maxerr(run_bus('Sine', 'lp', p, 512, N, K), f32(ref_bus)) < 2e-6, (vpt, span)
+        assert maxerr(run_bus('Sine', 'lp', p, 512, N, K), f32(ref_bus)) < bar(ref_bus, 2e-6), (vpt, span)
     hour = 172_800_000
     ref_bus = oracle_chain('Sine', 'lp', p, hour, N, 2) @ p['pan'].T
     geometry(1, 2, steady=1)
-    assert maxerr(run_bus('Sine', 'lp', p, hour, N, 2), f32(ref_bus)) < 2e-6
+    assert maxerr(run_bus('Sine', 'lp', p, hour, N, 2), f32(ref_bus)) < bar(ref_bus, 2e-6)
 
 
 def test_closed_form_kernel_block_sizes_and_bus_widths():
@@ -290,7 +297,7 @@ def test_mix_matrix_sink_equals_mix_matrix_over_the_stored_chain(kind):
                                              dev(p['gain']), M, closed)
                 closed = closed.cpu().numpy()
                 assert np.isfinite(closed).all() and maxerr(closed, want) < 1e-6 * scale, (V, N, K, pos, span, steady)
-                assert maxerr(closed, f32(ref)) < 2e-6 * scale, (V, N, K, pos, span, steady)
+                assert maxerr(closed, f32(ref)) < 1e-6 * max(1.0, scale), (V, N, K, pos, span, steady)
 
 
 def test_tile_sum_inside_the_kernel_equals_the_second_launch_bit_for_bit():
@@ -378,7 +385,7 @@ def test_one_launch_latency_kernel_matches_the_oracle(btype):
         for device_pos in (False, True, False):                       # three launches on one workspace: the counter re-arms
             got = run_latency(btype, p, pos, N, C=C, device_pos=device_pos, ws=ws)
             assert np.isfinite(got).all()
-            assert maxerr(got, want) < 2e-6 * max(1.0, float(np.abs(want).max())), (V, N, pos, C, device_pos)
+            assert maxerr(got, want) < 1e-6 * max(1.0, float(np.abs(want).max())), (V, N, pos, C, device_pos)
 
 
 def test_engine_latency_mode_uses_one_launch_and_follows_a_stream():
