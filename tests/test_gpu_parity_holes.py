@@ -204,7 +204,8 @@ if rank == 0:
         full = float(want.abs().max())
         err = float((got.double() - want.double()).abs().max())
         assert 0.05 < full < 50.0, (name, full)
-        assert err < 1e-7 * max(1.0, full), (name, err, full)
+        ulp = float(np.spacing(np.float32(full)))                  # the shards' float32 buses are summed in another order: one ulp of full scale
+        assert err < max(1e-7, 1.01 * ulp), (name, err, full)
         print('SHARD', name, 'err', err, 'full_scale', full)
 else:
     for got in (b,):                                    # the all-reduced bus is on every rank
