@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 5
+#define SIG_ABI_VERSION 6
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -278,7 +278,9 @@ int sig_advance_position(int64_t* position_dev, int64_t delta, void* stream);
  * SIG_CTL_MAX_INS = SIG_CTL_MAX_REGS: one register per instruction, the register file is sized by n_ins; a longer program is refused with
  * hipErrorInvalidValue) is that subgraph in evaluation order over registers dst < n_ins; thread (b, v) runs it for
  * block b (frame position + b * step) at column v < cols and writes register outs[k].reg to outs[k].out[b * outs[k].cols + v]
- * for v < outs[k].cols.  A register index of -1 reads 0.  Same expressions as sig_osc_bank (f64 store) and sig_elementwise,
+ * for v < outs[k].cols.  `position` may lie before `min_position` (even be negative): blocks whose frame position + b * step is below
+ * min_position are evaluated AT min_position (the virtual blocks in front of short blocks read their controls at max(p - context, 0);
+ * what feeds the last filter of a short block read them at an earlier block's position, never before the stream's second block).  A register index of -1 reads 0.  Same expressions as sig_osc_bank (f64 store) and sig_elementwise,
  * so the same bits as the node-by-node evaluation. */
 enum { SIG_CTL_ROW = 0, SIG_CTL_OSC = 1, SIG_CTL_GAIN = 2, SIG_CTL_MIX = 3, SIG_CTL_RINGMOD = 4, SIG_CTL_AMP = 5 };
 enum { SIG_CTL_MAX_REGS = 48, SIG_CTL_MAX_INS = 48 };
@@ -296,6 +298,7 @@ typedef struct { int32_t reg; int32_t cols; double* out; double* front; } sig_ct
 /* front_position >= 0: the program is evaluated once more, at that frame position, into the outputs' `front` rows (the
  * controls of the block in front of the batch -- sig_fused_*_fm's *_hist -- without a launch of their own); -1: not. */
 int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols, int64_t front_position,
+                        int64_t min_position,
                         const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream);
 
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
@@ -422,6 +425,68 @@ int sig_fused_voice_bus(int osc_kind, int filt_type, int32_t rate, int64_t posit
                         const double* gain, int32_t gain_stride,
                         const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
                         double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+
+/* A whole frame-rate voice graph in ONE launch (voice_program.hip): the general form of the fused entry points above, for
+ * the graph shapes none of them covers.  Replaces, for every voice of a graph at once, the bodies of
+ *   Osc._eval + _osc (osc.py:26-62), CritFilter._filter / _get_sos for LowPass / HighPass (fx.py:85-121), Gain / Mix / RingMod /
+ *   Amp._eval (fx.py:35-60), Fixed._eval as an audio operand (fixed.py:38-39), White._eval (noise.py:22-23), the build-defined
+ *   ADSR, and the sink: the rows themselves or the build-defined SumBus
+ * together with the block structure between them: every node reads its control ports once per block at the block's position
+ * (BoundPort.forward_at_block_rate, chain/__init__.py:305-306); a filter answers a block from zero state over
+ * [<= context rows | block] (fx.py:93-105, forward_with_context chain/__init__.py:308-315); the context rows in front of block j
+ * are the input's rows of block j - 1 as its block cache holds them (BlockCachingEmitter, chain/__init__.py:431-442), or -- on a
+ * fresh graph, and for EVERY block when blocks are shorter than the context -- the input rendered as a block of its own
+ * [p - context, p) with its controls read at max(p - context, 0).
+ *
+ * `program` (HOST memory, copied into the launch): the per-voice graph as straight-line code for an accumulator machine.
+ *   OSC    acc = wave_kind(n / rate * hertz[a] + phase[a])         oscillator slot a (hertz / phase rows below)
+ *   FILTER acc = filter slot a applied to acc                      (cutoff rows / type below; one slot per filter node)
+ *   GAIN   acc = acc * params[a]          AMP  acc = copysign(acc ** params[a], acc)          CONST  acc = params[a]
+ *   MUL    acc = temp[a] * acc            MIX  acc = m L + (1 - m) R, m = params[b], (L, R) = c ? (acc, temp[a]) : (temp[a], acc)
+ *   SAVE   temp[a] = acc                  LOAD acc = temp[a]
+ *   ADSR   acc = envelope level at n / rate (the six rows `adsr`)     NOISE acc = White sample (noise_seed[a], frame n, channel)
+ * The accumulator after the last instruction is the voice's sample of that row.  Rows (sig_vp_rows) are float64 (rows, voices | 1)
+ * arrays, col_stride 1 | 0: rows == 1 holds for every block; otherwise rows == control_rows, one row per block:
+ *   block_frames >= context:  [the block in front of the first history block | hist_blocks history blocks | nblocks blocks],
+ *                             control_rows = hist_blocks + 1 + nblocks
+ *   block_frames <  context:  [nblocks virtual blocks (controls read at max(p_b - context, 0)) | nblocks blocks], control_rows = 2 nblocks.
+ *                             There the rows a block's LAST filter reads over the block itself are the oldest cached reply of its input that
+ *                             contains them (chain/__init__.py:435-442): the reply to the `after` request made m_b = min((context -
+ *                             block_frames) / block_frames, blocks_before + b - 1) blocks earlier, at q_b = p_b - m_b block_frames (block 0 of
+ *                             a fresh graph: q = p) -- every node in front of the last filter read its controls THERE, so the caller
+ *                             evaluates their rows of the second group at q_b, those of the last filter and behind it at p_b.
+ *                             `blocks_before`: blocks of this size rendered contiguously in front of the launch since the graph was fresh.
+ *                             16 <= block_frames (below that the reference's 16-entry block cache evicts what a block reads), depth <= 2.
+ * `depth` = filters in series on the longest path to the sink.  `hist_positions[hist_blocks]` (ascending, < position): where the
+ * depth - 1 blocks in front of the launch start -- the previous render's blocks on a continuing stream, the virtual blocks
+ * p - context, p - 2 context ... (clipped at 0) on a fresh graph; ignored when block_frames < context (at most two filters in
+ * series there).  bus_channels 0: out (nblocks * block_frames, voices) float32; 1 | 2: out (.., bus_channels) = sum over voices of
+ * bus_gains[c, v] * sample (bus_gains NULL: mono sum), float64 accumulation in a fixed order; workspace of
+ * sig_fused_voice_bus_workspace(voices, rows, bus_channels) bytes.  f64 arithmetic, no float32 rounding between the nodes.
+ * A rejected filter design (fx.py:99-102) gives NaN rows and sets SIG_STATUS_BAD_CUTOFF. */
+enum { SIG_VP_OSC = 0, SIG_VP_FILTER = 1, SIG_VP_GAIN = 2, SIG_VP_MUL = 3, SIG_VP_MIX = 4, SIG_VP_SAVE = 5, SIG_VP_LOAD = 6,
+       SIG_VP_CONST = 7, SIG_VP_AMP = 8, SIG_VP_ADSR = 9, SIG_VP_NOISE = 10 };
+enum { SIG_VP_MAX_INS = 32, SIG_VP_MAX_OSCS = 4, SIG_VP_MAX_PARAMS = 8, SIG_VP_MAX_FILTERS = 4, SIG_VP_MAX_TEMPS = 4, SIG_VP_MAX_HIST = 3 };
+typedef struct { int32_t op, kind, a, b, c; } sig_vp_ins;
+typedef struct { const double* ptr; int32_t col_stride; int32_t rows; } sig_vp_rows;
+typedef struct {
+    int32_t n_ins; sig_vp_ins ins[SIG_VP_MAX_INS];
+    int32_t n_oscs; sig_vp_rows hertz[SIG_VP_MAX_OSCS], phase[SIG_VP_MAX_OSCS];     /* phase.ptr NULL: unplugged = 0 */
+    int32_t n_params; sig_vp_rows params[SIG_VP_MAX_PARAMS];
+    int32_t n_filters; sig_vp_rows cutoff[SIG_VP_MAX_FILTERS]; int32_t filter_type[SIG_VP_MAX_FILTERS];
+    int32_t filter_level[SIG_VP_MAX_FILTERS];                                       /* 1 + the filters in series in front of this one */
+    int32_t n_temps, depth;
+    const double* adsr[6]; int32_t adsr_stride[6];                                  /* attack decay sustain release gate_on gate_off */
+    uint64_t noise_seed[2];
+} sig_voice_program_t;
+int sig_voice_program(const sig_voice_program_t* program, int32_t rate, int64_t position, int32_t block_frames,
+                      int32_t nblocks, int32_t context, int32_t voices, int32_t control_rows,
+                      int32_t hist_blocks, const int64_t* hist_positions, int32_t blocks_before,
+                      const double* bus_gains, int64_t bus_gains_ld, int32_t bus_channels,
+                      double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream);
+/* Tuning / test hook: force the voices per lane (1, 2; 0 = heuristic; ignored where the program does not fit the variant) and
+ * the blocks per lane (0 = heuristic) of sig_voice_program.  Process-wide. */
+int sig_voice_program_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane);
 
 #ifdef __cplusplus
 }

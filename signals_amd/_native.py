@@ -20,7 +20,7 @@ OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
 FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 SINE_FAST_MAX_CYCLES = 2.0 ** 26     # sig_osc.h kSineFastMaxT: |t| up to which the fused Sine kernels advance the phase incrementally
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
@@ -32,7 +32,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_voice_bus_plan', 'sig_fused_set_tuning', 'sig_fused_voice_bus_walk',
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
-           'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program')
+           'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
+           'sig_voice_program', 'sig_voice_program_set_tuning')
 
 
 class NativeError(RuntimeError):
@@ -53,6 +54,30 @@ class CtlOut(ctypes.Structure):
 
 CTL_OPS = {'Row': 0, 'Osc': 1, 'Gain': 2, 'Mix': 3, 'RingMod': 4, 'Amp': 5}
 CTL_MAX_REGS, CTL_MAX_INS = 48, 48
+
+
+# ---- sig_voice_program: the per-voice graph as code for the accumulator machine of voice_program.hip
+VP_OPS = {'Osc': 0, 'Filter': 1, 'Gain': 2, 'Mul': 3, 'Mix': 4, 'Save': 5, 'Load': 6, 'Const': 7, 'Amp': 8, 'Adsr': 9, 'Noise': 10}
+VP_MAX_INS, VP_MAX_OSCS, VP_MAX_PARAMS, VP_MAX_FILTERS, VP_MAX_TEMPS, VP_MAX_HIST = 32, 4, 8, 4, 4, 3
+
+
+class VpIns(ctypes.Structure):
+    _fields_ = [('op', ctypes.c_int32), ('kind', ctypes.c_int32), ('a', ctypes.c_int32), ('b', ctypes.c_int32), ('c', ctypes.c_int32)]
+
+
+class VpRows(ctypes.Structure):
+    _fields_ = [('ptr', ctypes.c_void_p), ('col_stride', ctypes.c_int32), ('rows', ctypes.c_int32)]
+
+
+class VoiceProgramT(ctypes.Structure):
+    """sig_voice_program_t (host memory)"""
+    _fields_ = [('n_ins', ctypes.c_int32), ('ins', VpIns * VP_MAX_INS),
+                ('n_oscs', ctypes.c_int32), ('hertz', VpRows * VP_MAX_OSCS), ('phase', VpRows * VP_MAX_OSCS),
+                ('n_params', ctypes.c_int32), ('params', VpRows * VP_MAX_PARAMS),
+                ('n_filters', ctypes.c_int32), ('cutoff', VpRows * VP_MAX_FILTERS), ('filter_type', ctypes.c_int32 * VP_MAX_FILTERS),
+                ('filter_level', ctypes.c_int32 * VP_MAX_FILTERS),
+                ('n_temps', ctypes.c_int32), ('depth', ctypes.c_int32),
+                ('adsr', ctypes.c_void_p * 6), ('adsr_stride', ctypes.c_int32 * 6), ('noise_seed', ctypes.c_uint64 * 2)]
 
 
 class Operand(ctypes.Structure):
@@ -157,7 +182,12 @@ def lib() -> ctypes.CDLL:
         L.sig_fused_voice_bus_fm.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                              dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_control_program.restype = ctypes.c_int
-        L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, i64, vp, i32, vp, i32, vp]
+        L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp]
+        L.sig_voice_program.restype = ctypes.c_int
+        L.sig_voice_program.argtypes = [ctypes.POINTER(VoiceProgramT), i32, i64, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int64), i32,
+                                        dp, i64, i32, vp, vp, i64, vp, vp]
+        L.sig_voice_program_set_tuning.restype = ctypes.c_int
+        L.sig_voice_program_set_tuning.argtypes = [i32, i32]
         L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
         L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                 dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
@@ -767,11 +797,12 @@ def runtime_device():
 
 
 def control_program(rate: int, position: int, step: int, nblocks: int, cols: int, program: torch.Tensor, n_ins: int,
-                    outs: torch.Tensor, n_outs: int, front_position: int = -1) -> None:
+                    outs: torch.Tensor, n_outs: int, front_position: int = -1, min_position: int = 0) -> None:
     """run a block-rate control program (sig_control_program): `program` / `outs` are device byte tensors of CtlIns / CtlOut;
-    `front_position` >= 0 also evaluates it at that position into the outputs' `front` rows"""
+    `front_position` >= 0 also evaluates it at that position into the outputs' `front` rows; blocks whose position lies below
+    `min_position` are evaluated there"""
     _gpu(program, outs)
-    _check(lib().sig_control_program(rate, position, step, nblocks, cols, front_position, program.data_ptr(), n_ins,
+    _check(lib().sig_control_program(rate, position, step, nblocks, cols, front_position, min_position, program.data_ptr(), n_ins,
                                      outs.data_ptr(), n_outs, _stream(program)), 'sig_control_program')
 
 
@@ -909,3 +940,83 @@ def adsr_apply(position: int, rate: int, rows: dict, x: torch.Tensor, out: torch
     _check(lib().sig_adsr_apply(position, rate, out.shape[0], out.shape[1], ptrs, strides, x.data_ptr(), x.stride(0),
                                 out.data_ptr(), out.stride(0), _stream(out)), 'sig_adsr_apply')
     return out
+
+
+def _vp_rows(t: torch.Tensor | None, what: str, voices: int, control_rows: int) -> VpRows:
+    if t is None:
+        return VpRows(None, 0, 1)
+    if (t.dtype != torch.float64 or t.dim() != 2 or not t.is_contiguous() or t.shape[1] not in (1, voices)
+            or t.shape[0] not in (1, control_rows)):
+        raise NativeError(f'{what}: rows of a voice program are contiguous float64 (1|{control_rows}, 1|{voices}), got {tuple(t.shape)} {t.dtype}')
+    return VpRows(t.data_ptr(), 0 if t.shape[1] == 1 else 1, t.shape[0])
+
+
+def voice_program(code: list, oscs: list, params: list, filters: list, n_temps: int, depth: int, rate: int, position: int,
+                  block_frames: int, nblocks: int, context: int, voices: int, control_rows: int, hist_positions: list,
+                  out: torch.Tensor, bus_gains: torch.Tensor | None = None, bus: bool = False,
+                  adsr: dict | None = None, noise_seeds: tuple = (0, 0), workspace: torch.Tensor | None = None,
+                  status: torch.Tensor | None = None, blocks_before: int = 0) -> torch.Tensor:
+    """One launch for a whole per-voice graph (sig_voice_program).  `code`: (op name, kind, a, b, c) tuples; `oscs`: (hertz,
+    phase | None) row tensors per oscillator slot; `params`: row tensors per parameter register; `filters`: (cutoff rows,
+    'lp' | 'hp', level = 1 + the filters in series in front of it) per filter slot.  Rows are float64 (1 | control_rows, 1 | voices).  out (nblocks * block_frames, voices) float32,
+    or with `bus` (.., C) = the sum over voices weighted by bus_gains."""
+    tensors = [t for pair in oscs for t in pair] + list(params) + [f[0] for f in filters] + list((adsr or {}).values())
+    _gpu(out, bus_gains, workspace, status, *tensors)
+    _audio(out, 'voice program out')
+    rows = block_frames * nblocks
+    if out.dtype != torch.float32 or out.shape[0] != rows:
+        raise NativeError(f'voice program out must be float32 ({rows}, .), got {tuple(out.shape)} {out.dtype}')
+    if len(code) > VP_MAX_INS or len(oscs) > VP_MAX_OSCS or len(params) > VP_MAX_PARAMS or len(filters) > VP_MAX_FILTERS \
+            or n_temps > VP_MAX_TEMPS or len(hist_positions) > VP_MAX_HIST:
+        raise NativeError('voice program larger than the machine')
+    P = VoiceProgramT()
+    P.n_ins = len(code)
+    for k, (op, kind, a, b, c) in enumerate(code):
+        P.ins[k] = VpIns(VP_OPS[op], kind, a, b, c)
+    P.n_oscs = len(oscs)
+    for k, (hz, ph) in enumerate(oscs):
+        P.hertz[k] = _vp_rows(hz, 'hertz', voices, control_rows)
+        P.phase[k] = _vp_rows(ph, 'phase', voices, control_rows)
+    P.n_params = len(params)
+    for k, t in enumerate(params):
+        P.params[k] = _vp_rows(t, 'parameter', voices, control_rows)
+    P.n_filters = len(filters)
+    for k, (cut, btype, level) in enumerate(filters):
+        if cut.shape[1] != voices and voices != 1:
+            raise IndexError(f'index {cut.shape[1]} is out of bounds for axis 1 with size {cut.shape[1]}')      # fx.py:99
+        P.cutoff[k] = _vp_rows(cut, 'cutoff', voices, control_rows)
+        P.filter_type[k] = FILT_TYPES[btype]
+        P.filter_level[k] = level
+    P.n_temps, P.depth = n_temps, depth
+    if adsr is not None:
+        for i, name in enumerate(ADSR_PARAMS):
+            P.adsr[i], P.adsr_stride[i] = _ctrl_row(adsr[name], name)
+            if adsr[name].shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {adsr[name].shape[1]} channels for {voices} voices')
+    P.noise_seed[0], P.noise_seed[1] = noise_seeds
+    hist = (ctypes.c_int64 * max(1, len(hist_positions)))(*hist_positions)
+    C = 0
+    gp, gld = None, 0
+    if bus:
+        C = out.shape[1]
+        if bus_gains is not None:
+            if bus_gains.dtype != torch.float64 or bus_gains.shape != (C, voices) or bus_gains.stride(1) != 1:
+                raise NativeError(f'bus gains must be float64 ({C},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+            gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+        elif C != 1:
+            raise NativeError('a bus without gains is mono')
+        need = lib().sig_fused_voice_bus_workspace(voices, rows, C)
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
+    elif out.shape[1] != voices:
+        raise NativeError(f'voice program out has {out.shape[1]} channels for {voices} voices')
+    _check(lib().sig_voice_program(ctypes.byref(P), rate, position, block_frames, nblocks, context, voices, control_rows,
+                                   len(hist_positions), hist, blocks_before, gp, gld, C,
+                                   workspace.data_ptr() if workspace is not None else None, out.data_ptr(), out.stride(0),
+                                   status.data_ptr() if status is not None else None, _stream(out)), 'sig_voice_program')
+    return out
+
+
+def set_voice_program_tuning(voices_per_lane: int = 0, blocks_per_lane: int = 0) -> None:
+    """tuning / test hook (process-wide): force `voice_program`'s launch geometry; the defaults restore the heuristic"""
+    _check(lib().sig_voice_program_set_tuning(voices_per_lane, blocks_per_lane), 'sig_voice_program_set_tuning')

@@ -25,7 +25,7 @@ constexpr int kThreads = 128;
 // column chunk -- a vibrato + sweep + tremolo program over 1024 blocks x 1024 voices took 65 us with every (block, column)
 // thread running all 26 instructions, three f64 sines among them.
 __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, int64_t position, int64_t step, int nblocks, int cols,
-                                                                   int64_t front_position,
+                                                                   int64_t front_position, int64_t min_position,
                                                                    const sig_ctl_ins* __restrict__ program, int n_ins,
                                                                    const sig_ctl_out* __restrict__ outs, int n_outs)
 {
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
         switch (ins.op) {
             case SIG_CTL_ROW: x = row_value(ins, v); break;
             case SIG_CTL_OSC: {
-                const double t = (double)(position + b * step) / rate * get(ins.a) + get(ins.b);      // osc.py:32
+                int64_t frame = position + b * step;
+                if (!front && frame < min_position) frame = min_position;      // (the first blocks of a run that starts before min_position are evaluated there)
+                const double t = (double)frame / rate * get(ins.a) + get(ins.b);      // osc.py:32
                 switch (ins.kind) {
                     case SIG_OSC_SINE: x = sig_osc::osc_sine(t); break;
                     case SIG_OSC_SQUARE: x = sig_osc::osc_square(t); break;
@@ -105,17 +107,17 @@ __global__ __launch_bounds__(kThreads) void control_program_kernel(double rate, 
 }  // namespace
 
 extern "C" int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
-                                   int64_t front_position,
+                                   int64_t front_position, int64_t min_position,
                                    const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream)
 {
-    SIG_CHECK_ARG(rate > 0 && position >= 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0 && front_position >= -1);
+    SIG_CHECK_ARG(rate > 0 && step >= 0 && nblocks >= 0 && cols >= 1 && n_ins >= 0 && n_outs >= 0 && front_position >= -1 && min_position >= 0);
     SIG_CHECK_ARG((program || n_ins == 0) && (outs || n_outs == 0) && n_ins <= SIG_CTL_MAX_INS);
     if ((nblocks == 0 && front_position < 0) || n_outs == 0) return 0;
     // one register per instruction (dst < n_ins): the program lives in device memory, so register indices cannot be checked
     // here -- the LDS register file is sized by n_ins, and n_ins <= SIG_CTL_MAX_INS == SIG_CTL_MAX_REGS was checked above
     static_assert(SIG_CTL_MAX_INS <= SIG_CTL_MAX_REGS, "the register file is sized by the instruction count");
     const int n_regs = n_ins > 0 ? n_ins : 1;
-    control_program_kernel<<<(unsigned)(nblocks + (front_position >= 0 ? 1 : 0)), kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols, front_position,
+    control_program_kernel<<<(unsigned)(nblocks + (front_position >= 0 ? 1 : 0)), kThreads, (size_t)n_regs * kThreads * sizeof(double), static_cast<hipStream_t>(stream)>>>((double)rate, position, step, nblocks, cols, front_position, min_position,
                                                                                           program, n_ins, outs, n_outs);
     return sig_launch_status();
 }

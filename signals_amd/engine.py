@@ -154,10 +154,12 @@ class BatchRenderer:
     node (tails), the device status words of its filters, and the replay closure of a one-launch plan."""
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
-                 fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False):
+                 fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
+        `fuse_program` (default: as `fuse`): graphs none of the fused kernels covers run as one interpreted launch per sink
+        (sig_voice_program) instead of one kernel per node.
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -179,6 +181,9 @@ class BatchRenderer:
         self._virtual_history: set = set()                 # bus nodes whose launch of THIS batch kept its filter history implicit (no tails)
         self._cascade_stream: set = set()                  # ... of the previous batch, when this one continues it
         self._tails_rebuilt = False                        # the previous block was re-rendered per node for this batch's tails
+        self._recent_blocks: list[tuple[int, int]] = []    # (start, end) of the last few blocks of the contiguous stream rendered so far
+        self._stream_blocks = 0                            # blocks of the CURRENT size rendered contiguously since the stream started
+        self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)   # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program)
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -206,6 +211,10 @@ class BatchRenderer:
         continuing = self._stream_end == position and (bool(self._tails) or bool(self._virtual_history))
         if not continuing:
             self._tails.clear()
+        if self._stream_end != position or self._prev_block_frames != block_frames:
+            self._stream_blocks = 0                        # (what a block of another size left in the reference's caches is not modelled: a fresh stream)
+        if self._stream_end != position:
+            self._recent_blocks = []
         self._cascade_stream = self._virtual_history if continuing else set()    # buses the previous batch ran through the fused cascade
         self._virtual_history = set()                      # filled again by launches that keep their history implicit (fused cascade)
         self._tails_rebuilt = False
@@ -216,7 +225,30 @@ class BatchRenderer:
             self._tails[node] = (position + block_frames * nblocks, buf[buf.shape[0] - keep:].clone())
         self._stream_end = position + block_frames * nblocks
         self._prev_block_frames = block_frames
+        self._stream_blocks += nblocks
+        if block_frames >= CONTEXT:
+            first = max(0, nblocks - 4)
+            self._recent_blocks = (self._recent_blocks + [(position + b * block_frames, position + (b + 1) * block_frames)
+                                                          for b in range(first, nblocks)])[-4:]
+        else:
+            self._recent_blocks = []
         return out
+
+    def history_starts(self, position: int, count: int) -> list[int]:
+        """where the `count` blocks in front of `position` start, oldest first: the previous renders' blocks while the stream is
+        contiguous, then -- a fresh graph -- the virtual blocks the reference's context requests create, [p - 100, p) answered
+        as a block of its own (chain/__init__.py:149-153, :431-442), clipped at 0.  Fewer than `count` when position 0 is reached."""
+        starts = []
+        edge = position
+        for start, end in reversed(self._recent_blocks):
+            if end != edge or len(starts) == count:
+                break
+            starts.insert(0, start)
+            edge = start
+        while len(starts) < count and edge > 0:
+            edge = max(edge - CONTEXT, 0)
+            starts.insert(0, edge)
+        return starts
 
     def _rebuild_tails(self, position: int) -> None:
         """The previous batch ran (part of) the graph through the fused cascade, which leaves no tails, and this one needs
@@ -243,6 +275,8 @@ class BatchRenderer:
     def reset(self) -> None:
         self._tails.clear()
         self._virtual_history = set()
+        self._recent_blocks = []
+        self._stream_blocks = 0
         self._stream_end = None
         self._replay = None
         self._captured = None
@@ -334,8 +368,12 @@ class _ControlProgram:
     (an edited value re-uploads into a new tensor: recompile).  Outputs are owned by the program and overwritten by the
     next run -- their consumers are launches enqueued before that on the same stream."""
 
-    def __init__(self, srcs: tuple, K: int):
+    def __init__(self, srcs: tuple, K: int, lead: int = 0, into: dict | None = None):
+        """`lead`: every computed output is rows [lead:] of a (lead + K, cols) buffer `self.full[i]` whose row lead - 1 is the
+        `front` row -- the layout sig_voice_program takes its per-block rows in ([rows in front | K blocks]); `into`: {source
+        index: (K, cols) tensor} to write into instead of buffers of its own (rows of another program's `full`)"""
         self.srcs, self.K = srcs, K
+        self.full: dict[int, torch.Tensor] = {}
         self.ins: list = []
         self.keep: list[torch.Tensor] = []                  # tensors the instructions point into
         self.fixed: list[tuple[fixed.Fixed, torch.Tensor]] = []
@@ -354,11 +392,21 @@ class _ControlProgram:
                 self.results.append(None)                   # its resident row, fetched per run
             else:
                 reg, cols = self._emit(src)
-                out = torch.empty((K, cols), dtype=CTRL_DTYPE, device=dev)
-                front = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
+                i = len(self.results)
+                if into is not None:
+                    out = into[i]
+                    if tuple(out.shape) != (K, cols) or not out.is_contiguous():
+                        raise NotBatchable('control rows of another width than the buffer they go into')
+                    front = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
+                elif lead:
+                    self.full[i] = torch.empty((lead + K, cols), dtype=CTRL_DTYPE, device=dev)
+                    out, front = self.full[i][lead:], self.full[i][lead - 1:lead]
+                else:
+                    out = torch.empty((K, cols), dtype=CTRL_DTYPE, device=dev)
+                    front = torch.empty((1, cols), dtype=CTRL_DTYPE, device=dev)
                 outs.append(_native.CtlOut(reg, cols, out.data_ptr(), front.data_ptr()))
                 self.results.append(out)
-                self.fronts[len(self.results) - 1] = front
+                self.fronts[i] = front
         self.cols = max([c for _, c in self._reg.values()] + [1])
         # Row instructions first (they depend on nothing; the kernel keeps the one-column ones' loads four in flight), registers renumbered
         row_op = _native.CTL_OPS['Row']
@@ -419,12 +467,12 @@ class _ControlProgram:
     def current(self) -> bool:
         return all(f.resident() is t for f, t in self.fixed)
 
-    def run(self, owner, rate: int, position: int, step: int, front_position: int = -1):
+    def run(self, owner, rate: int, position: int, step: int, front_position: int = -1, min_position: int = 0):
         """the K-row replies; with `front_position` also the (1, cols) replies at that position -> (rows, fronts)"""
         if self.n_outs:
             owner._launch('control_program[block-rate]',
                           lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
-                                                          self.outs_t, self.n_outs, front_position), units=self.K * self.cols)
+                                                          self.outs_t, self.n_outs, front_position, min_position), units=self.K * self.cols)
         rows = [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
         if any(t.shape[0] not in (1, self.K) or (r is None and t.shape[0] != 1) for t, r in zip(rows, self.results)):
             raise NotBatchable('multi-row Fixed on a control port')             # (edited since the program was compiled)
@@ -573,6 +621,8 @@ class _Batch:
         rows = hist + self.N * self.K
 
         result = _VoiceChain.match_and_launch(self, node, channels, hist) if self.owner.fuse else None
+        if result is None and self.owner.fuse_program and hist == 0 and isinstance(node, _VoiceProgram.KERNEL_NODES):
+            result = self._program_store(node, channels)
         if result is None:
             for types, build in self._SCHEDULES:
                 if isinstance(node, types):
@@ -712,6 +762,8 @@ class _Batch:
                 src_port = top.left
                 self._require(src_port.sig, voices, hist)
         fused = self._bus_over_cascade(node, src_port, gains, rows) if o.fuse_cascade and hist == 0 else None
+        if fused is None and o.fuse_program and hist == 0:
+            fused = self._program_bus(node, src_port, gains, rows)
         if fused is None:
             fused = self._bus_over_filter(node, src_port, gains, hist, rows) if o.fuse and hist == 0 else None
         if fused is not None:
@@ -721,6 +773,49 @@ class _Batch:
             raise NotBatchable('SumBus over a one-row input')
         result = torch.empty((rows, node.channels), dtype=AUDIO_DTYPE, device=runtime.device())
         return o._launch('sum_bus', lambda: _native.sum_bus(x, gains, result), units=rows * x.shape[1])
+
+    def _program_store(self, node, channels):
+        """the per-voice graph under `node` as one interpreted launch (sig_voice_program) storing its rows, or None"""
+        memo_keys = {k[0] for k in self._memo}
+        prog = _VoiceProgram.compile(self, node, channels)
+        if prog is None or any(n in memo_keys for n in prog.uses if n is not node):
+            return None                                                        # (an inner node already has rows in this batch: someone else reads it)
+        # the node's natural width: every control row is one column wide -> the reply is (rows, 1), broadcast by the consumer
+        try:
+            tensors = [c if c is not None else self._control_const(p, p.name) if _ctl_const(p) else None for p, c, _ in prog.controls]
+        except NotBatchable:
+            return None
+        wide = any(t is None or t.shape[1] > 1 for t in tensors) or any(isinstance(n, (noise.White, ext.ADSR)) for n in prog.uses)
+        voices = channels if wide else 1
+        if voices != channels:
+            prog = _VoiceProgram.compile(self, node, voices)
+            if prog is None:
+                return None
+        out = torch.empty((self.N * self.K, voices), dtype=AUDIO_DTYPE, device=runtime.device())
+        try:
+            return prog.launch(out, None, False, f'voice_program[{prog.describe()}]')
+        except (_NoProgram, NotBatchable):
+            return None                                                        # (the per-node schedule decides: it may refuse the batch as a whole)
+
+    def _program_bus(self, node, src_port, gains, rows):
+        """SumBus over a per-voice graph no fused kernel covers: graph and bus in one interpreted launch, or None"""
+        voices, C = src_port.channels, node.channels
+        if C not in (1, 2) or voices is None or (gains is not None and gains.shape[1] != voices):
+            return None
+        memo_keys = {k[0] for k in self._memo}
+        prog = _VoiceProgram.compile(self, src_port.sig, voices)
+        if prog is None or any(n in memo_keys for n in prog.uses):
+            return None
+        if len(src_port.sig.outputs_with_ports) != 1:
+            return None                                                        # (the bus input has another reader: its rows must exist)
+        out = torch.empty((rows, C), dtype=AUDIO_DTYPE, device=runtime.device())
+        try:
+            result = prog.launch(out, gains, True, f'voice_program_bus[{prog.describe()}]')
+        except (_NoProgram, NotBatchable):
+            return None
+        if prog.depth:
+            self.owner._virtual_history.add(node)
+        return result
 
     def _bus_over_cascade(self, node, src_port, gains, rows):
         """SumBus([RingMod(] Filter2(Filter1(Osc)) [, ADSR)]) with block-invariant controls and no other reader of any of
@@ -1368,6 +1463,299 @@ class _VoiceChain:
         if node is o.node:
             o._remember_replay(N, K, replay)
         return run(b.pos, controls, pan, torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev))
+
+
+class _NoProgram(Exception):
+    """this graph is not one voice program"""
+
+
+class _ProgramRows:
+    """The per-block rows of a voice program's computed control ports, laid out as sig_voice_program takes them, each port one
+    (control_rows, cols) buffer filled by block-rate control programs (sig_control_program) that write straight into it:
+      blocks >= context:  [the block in front | H history blocks | K blocks]   -- the K rows and the row in front of them in one
+                          launch, one more launch of one row per further row in front;
+      blocks <  context:  [K virtual blocks, controls at max(p - context, 0) | K blocks]; the second group evaluated at the
+                          blocks' own positions (`inner` False) or where the oldest cached reply containing the block was
+                          evaluated (`inner`: the ports in front of the voice's last filter; header of sig_voice_program)."""
+
+    def __init__(self, srcs: tuple, K: int, lead: int, small: bool):
+        self.srcs, self.K, self.lead, self.small = srcs, K, lead, small
+        if not small:
+            self.main = _ControlProgram(srcs, K, lead=lead)
+            self.full = self.main.full
+            self.front = [_ControlProgram(srcs, 1, into={i: t[j:j + 1] for i, t in self.full.items()}) for j in range(lead - 1)]
+        else:
+            probe = _ControlProgram(srcs, K, lead=K)                           # rows [K:] of (2 K, cols) buffers: the blocks themselves
+            self.main, self.full = probe, probe.full
+            self.virtual = _ControlProgram(srcs, K, into={i: t[:K] for i, t in self.full.items()})
+            self.first = _ControlProgram(srcs, 1, into={i: t[K:K + 1] for i, t in self.full.items()})
+
+    def current(self) -> bool:
+        return self.main.current()
+
+    def tensors(self) -> list:
+        """per source: its rows -- the filled buffer, or the resident (1, cols) row of a Fixed / an unplugged port"""
+        return [self.full.get(i, r if r is not None else as_control(src.resident()))
+                for i, (src, r) in enumerate(zip(self.srcs, self.main.results))]
+
+
+class _VoiceProgram:
+    """The per-voice graph under a node as ONE launch of sig_voice_program (voice_program.hip): oscillators, LowPass / HighPass,
+    Gain / Amp / Mix / RingMod, Fixed rows, ADSR, White, in any arrangement in which every voice is computed from its own
+    parameters only (nothing mixes channels in front of the sink) and no inner node has a reader outside the graph.  Compiled
+    here into straight-line code for the kernel's accumulator machine: a binary node parks its left operand in a temporary, a
+    node with several readers is computed once and kept in one.  Control ports driven by computed block-rate signals become
+    per-block rows (`_ProgramRows`).  The block history stays implicit: the launch re-walks the blocks in
+    front of it from where the reference cold-started them, so no tails are kept for what it covers."""
+
+    KERNEL_NODES = (osc.Osc, fx.SingleCritFilter, fx.Gain, fx.Amp, fx.Mix, fx.RingMod, ext.ADSR, noise.White)
+
+    def __init__(self, batch: '_Batch', top: Emitter, voices: int):
+        self.batch, self.top, self.voices = batch, top, voices
+        self.code: list = []
+        self.oscs: list = []                     # (hertz control index, phase control index | None)
+        self.params: list = []                   # control index per parameter register
+        self.filters: list = []                  # (cutoff control index, type, level, node)
+        self.controls: list = []                 # (port | None, constant tensor | None, filters between the node and the sink)
+        self.adsr = None
+        self.seeds: list = []
+        self.temps_used, self.temps_free, self.n_temps = set(), [], 0
+        self.saved: dict = {}                    # node -> [temporary, readers left]
+        self.depth_of: dict = {}
+        self.uses: dict = {}
+        self.kernel_nodes = 0
+        self._count(top)
+        for n, uses in self.uses.items():
+            if n is not top and len(n.outputs_with_ports) != uses:
+                raise _NoProgram(f'{n.cls_name()} has a reader outside the graph')
+        self.depth = self._emit(top, 0)
+        if len(self.code) > _native.VP_MAX_INS:
+            raise _NoProgram('program too long')
+
+    # ---- pass 1: readers of every node inside the graph
+    def _count(self, n):
+        if n is None or not n.get_state().enabled:
+            if isinstance(n, ext.Tap):
+                self._count(n.input.sig)
+            return
+        if isinstance(n, ext.Tap):
+            return self._count(n.input.sig)
+        self.uses[n] = self.uses.get(n, 0) + 1
+        if self.uses[n] > 1:
+            return
+        if isinstance(n, self.KERNEL_NODES):
+            self.kernel_nodes += 1
+        elif not isinstance(n, fixed.Fixed):
+            raise _NoProgram(f'no voice-program instruction for {n.cls_name()}')
+        for port in _audio_ports(n):
+            self._count(port.sig)
+
+    # ---- pass 2: code
+    def _control(self, port, below: int, optional: bool = False):
+        src = port.sig
+        if src is None or not src.get_state().enabled:
+            if optional:
+                return None
+            self.controls.append((None, Emitter.empty_result(), below))
+        else:
+            self.controls.append((port, None, below))
+        return len(self.controls) - 1
+
+    def _param(self, index: int) -> int:
+        if len(self.params) >= _native.VP_MAX_PARAMS:
+            raise _NoProgram('more parameter registers than the machine has')
+        self.params.append(index)
+        return len(self.params) - 1
+
+    def _temp(self) -> int:
+        if self.temps_free:
+            t = self.temps_free.pop()
+        else:
+            t = self.n_temps
+            self.n_temps += 1
+            if self.n_temps > _native.VP_MAX_TEMPS:
+                raise _NoProgram('more temporaries than the machine has')
+        return t
+
+    def _zero(self, below: int) -> int:
+        self.controls.append((None, Emitter.empty_result(), below))
+        self.code.append(('Const', 0, self._param(len(self.controls) - 1), 0, 0))
+        return 0
+
+    def _emit(self, n, below: int) -> int:
+        """code that leaves the node's sample in the accumulator; returns the filters in series up to and including it"""
+        if isinstance(n, ext.Tap):
+            return self._emit(n.input.sig, below)                              # a pass-through, enabled or not
+        if n is None or not n.get_state().enabled:
+            return self._zero(below)                                           # zeros((1, 1)) (chain/__init__.py:250-254, :297-298)
+        if n in self.saved:
+            slot = self.saved[n]
+            self.code.append(('Load', 0, slot[0], 0, 0))
+            slot[1] -= 1
+            if slot[1] == 0:
+                self.temps_free.append(slot[0])
+                del self.saved[n]
+            return self.depth_of[n]
+        if isinstance(n, fixed.Fixed):
+            row = n.resident()
+            if row.shape[0] != 1:
+                raise _NoProgram('multi-row Fixed as an audio source')
+            self.controls.append((None, as_control(row), below))
+            self.code.append(('Const', 0, self._param(len(self.controls) - 1), 0, 0))
+            depth = 0
+        elif isinstance(n, osc.Osc):
+            if len(self.oscs) >= _native.VP_MAX_OSCS:
+                raise _NoProgram('more oscillators than the machine has slots')
+            self.oscs.append((self._control(n.hertz, below), self._control(n.phase, below, optional=True)))
+            self.code.append(('Osc', _native.OSC_KINDS[n.kind()], len(self.oscs) - 1, 0, 0))
+            depth = 0
+        elif isinstance(n, noise.White):
+            if len(self.seeds) >= 2 or n.channels != self.voices:
+                raise _NoProgram('White: two per program, as wide as the voices')
+            self.seeds.append(int(n.get_state().seed))
+            self.code.append(('Noise', 0, len(self.seeds) - 1, 0, 0))
+            depth = 0
+        elif isinstance(n, ext.ADSR):
+            if (self.adsr is not None and self.adsr is not n) or _modulated(n):
+                raise _NoProgram('one block-invariant envelope per program')
+            self.adsr = n
+            self.code.append(('Adsr', 0, 0, 0, 0))
+            depth = 0
+        elif isinstance(n, (fx.Gain, fx.Amp)):
+            depth = self._emit(n.left.sig, below)
+            self.code.append(('Gain' if isinstance(n, fx.Gain) else 'Amp', 0, self._param(self._control(n.right, below)), 0, 0))
+        elif isinstance(n, (fx.Mix, fx.RingMod)):
+            left = self._emit(n.left.sig, below)
+            t = self._temp()
+            self.code.append(('Save', 0, t, 0, 0))
+            right = self._emit(n.right.sig, below)
+            if isinstance(n, fx.Mix):
+                self.code.append(('Mix', 0, t, self._param(self._control(n.mix, below)), 0))      # m T + (1 - m) acc  (fx.py:40)
+            else:
+                self.code.append(('Mul', 0, t, 0, 0))
+            self.temps_free.append(t)
+            depth = max(left, right)
+        elif isinstance(n, fx.SingleCritFilter):
+            src = n.input.sig
+            if src is None or not src.get_state().enabled:
+                raise _NoProgram('filter without an input')                    # (the per-node schedule raises the reference's error)
+            depth = self._emit(src, below + 1) + 1
+            if len(self.filters) >= _native.VP_MAX_FILTERS:
+                raise _NoProgram('more filters than the machine has slots')
+            self.filters.append((self._control(n.cutoff, below), str(n.type()), depth, n))
+            self.code.append(('Filter', 0, len(self.filters) - 1, 0, 0))
+        else:
+            raise _NoProgram(f'no voice-program instruction for {n.cls_name()}')
+        self.depth_of[n] = depth
+        if self.uses.get(n, 1) > 1:                                            # several readers: computed once, kept in a temporary
+            t = self._temp()
+            self.code.append(('Save', 0, t, 0, 0))
+            self.saved[n] = [t, self.uses[n] - 1]
+        return depth
+
+    # ---- control rows and the launch
+    def _rows(self):
+        """(per control: its row tensor, control_rows, history block starts, blocks rendered before) or None"""
+        b, o = self.batch, self.batch.owner
+        N, K, pos = b.N, b.K, b.pos
+        small = self.depth > 0 and N < CONTEXT
+        if small and (self.depth > 2 or N < 16):
+            raise NotBatchable('short blocks: two filters in series at most, 16 frames at least')
+        want = max(self.depth - 1, 0)
+        if small:
+            hist, front, lead = [], 0, K
+        else:
+            starts = o.history_starts(pos, want + 1)
+            hist = starts[len(starts) - want:] if want else []
+            front = starts[len(starts) - want - 1] if len(starts) > want else 0
+            lead = len(hist) + 1
+        control_rows = 2 * K if small else lead + K
+        tensors: list = [None] * len(self.controls)
+        groups: dict = {}
+        for i, (port, const, below) in enumerate(self.controls):
+            if const is not None:
+                tensors[i] = const
+            elif _ctl_const(port):
+                tensors[i] = b._control_const(port, port.name)
+            else:
+                if small and below >= 2:
+                    raise NotBatchable('short blocks: block-rate control in front of two filters in series')
+                groups.setdefault(bool(small and below >= 1), []).append(i)
+        for inner, members in groups.items():
+            srcs = tuple(self.controls[i][0].sig for i in members)
+            key = ('voice-program', tuple(id(x) for x in srcs), K, lead, small)
+            held = o._ctl_programs.get(key)
+            if held is None or held[0] != graph_clock.version or not held[1].current():
+                if len(o._ctl_programs) > 16:
+                    o._ctl_programs.clear()
+                held = o._ctl_programs[key] = (graph_clock.version, _ProgramRows(srcs, K, lead, small))
+            rows = held[1]
+            if not small:
+                ahead = [front] + hist                                         # where the rows in front of the K blocks are read
+                rows.main.run(o, b.rate, pos, N, front_position=ahead[lead - 1])       # (the last of them in the same launch)
+                for j, sub in enumerate(rows.front):
+                    sub.run(o, b.rate, ahead[j], 0)
+            else:
+                rows.virtual.run(o, b.rate, pos - CONTEXT, N)
+                if not inner:
+                    rows.main.run(o, b.rate, pos, N)
+                else:
+                    # what feeds the last filter over block b was evaluated m_b = min((100 - N) / N, blocks before it - 1) blocks
+                    # earlier (the oldest cached `after` reply containing the block), never before the stream's second block
+                    mmax = (CONTEXT - N) // N
+                    first = pos - o._stream_blocks * N
+                    rows.main.run(o, b.rate, pos - mmax * N, N, min_position=first + N)
+                    if o._stream_blocks == 0:
+                        rows.first.run(o, b.rate, pos, 0)                      # ... the stream's very first block at its own position
+            for i, t in zip(members, rows.tensors()):
+                tensors[i] = as_control(t)
+        return tensors, control_rows, hist, (o._stream_blocks if small else 0)
+
+    def launch(self, out: torch.Tensor, bus_gains: torch.Tensor | None, bus: bool, label: str) -> torch.Tensor:
+        b, o = self.batch, self.batch.owner
+        tensors, control_rows, hist, before = self._rows()
+        v = self.voices
+        widths = [t.shape[1] for t in tensors]
+        if any(w not in (1, v) for w in widths):
+            raise _NoProgram('control rows of another width than the voices')
+        for cut, _, _, _ in self.filters:
+            if tensors[cut].shape[1] != v and v != 1:
+                raise IndexError(f'index {tensors[cut].shape[1]} is out of bounds for axis 1 with size {tensors[cut].shape[1]}')   # fx.py:99
+        adsr = None
+        if self.adsr is not None:
+            adsr = self.adsr.control_rows(lambda bound: b._control_const(bound, bound.name))
+            if any(r.shape[1] not in (1, v) for r in adsr.values()):
+                raise _NoProgram('envelope rows of another width than the voices')
+        oscs = [(tensors[h], tensors[p] if p is not None else None) for h, p in self.oscs]
+        params = [tensors[i] for i in self.params]
+        filters = [(tensors[c], t, level) for c, t, level, _ in self.filters]
+        status = o._status_word(self.filters[0][3]) if self.filters else None
+        if bus:
+            need = _native.lib().sig_fused_voice_bus_workspace(v, out.shape[0], out.shape[1]) // 8
+            if o._workspace is None or o._workspace.numel() < need:
+                o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=runtime.device())
+        seeds = tuple(self.seeds + [0, 0])[:2]
+        if self.depth:
+            o._virtual_history.add(self.top)
+        return o._launch(label, lambda: _native.voice_program(self.code, oscs, params, filters, self.n_temps, self.depth, b.rate, b.pos,
+                                                              b.N, b.K, CONTEXT, v, control_rows, hist, out, bus_gains=bus_gains, bus=bus,
+                                                              adsr=adsr, noise_seeds=seeds, workspace=o._workspace if bus else None,
+                                                              status=status, blocks_before=before),
+                         units=out.shape[0] * v)
+
+    @classmethod
+    def compile(cls, batch: '_Batch', top: Emitter, voices: int):
+        """the program, or None when the graph is not one (or is a single kernel anyway)"""
+        if top is None or not top.get_state().enabled:
+            return None
+        try:
+            prog = cls(batch, top, voices)
+        except _NoProgram:
+            return None
+        return prog if prog.kernel_nodes >= 2 else None
+
+    def describe(self) -> str:
+        return ','.join(op for op, *_ in self.code)
 
 
 _KNOWN_TYPES = tuple(t for types, _ in _Batch._SCHEDULES for t in (types if isinstance(types, tuple) else (types,)))

@@ -32,7 +32,7 @@ def test_header_and_binding_agree():
 def test_every_declared_symbol_is_exported(lib):
     for name in declared_symbols():
         assert getattr(lib, name) is not None, name
-    assert lib.sig_abi_version() == 5
+    assert lib.sig_abi_version() == 6
 
 
 def test_argument_errors_do_not_reach_the_device(lib):
@@ -52,10 +52,10 @@ def test_argument_errors_do_not_reach_the_device(lib):
     # a control program longer than its register file (one register per instruction, SIG_CTL_MAX_INS == SIG_CTL_MAX_REGS == 48)
     lib.sig_control_program.restype = ctypes.c_int
     lib.sig_control_program.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
-                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
-    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 16, 49, 16, 1, None) == inv
-    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 16, 64, 16, 1, None) == inv
-    assert lib.sig_control_program(48000, 0, 256, 0, 8, -1, 16, 48, 16, 1, None) == 0             # accepted; no blocks: no launch
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 0, 16, 49, 16, 1, None) == inv
+    assert lib.sig_control_program(48000, 0, 256, 4, 8, -1, 0, 16, 64, 16, 1, None) == inv
+    assert lib.sig_control_program(48000, 0, 256, 0, 8, -1, 0, 16, 48, 16, 1, None) == 0             # accepted; no blocks: no launch
 
 
 def test_fused_geometry_needs_no_device():

@@ -310,14 +310,20 @@ def test_fused_voice_chain_vs_golden_and_unfused(golden):
             gn = fx.Gain(); gn.left = flt; gn.right = fix([[0.5]])
             return gn
         assert maxerr(batched(build(), 77, N, K, V, fuse=True), batched(build(), 77, N, K, V)) < 3e-7, (V, N, K, kind)
-    # a second consumer of the oscillator forbids fusing it away
+    # a second consumer of the oscillator forbids fusing it away in the chain kernel: the whole graph is one voice program
+    # (the oscillator kept in a temporary); without it, one kernel per node, bit-identical to the eager path
     o = mkosc('Sine', g['c2/hertz'], g['c2/phase'])
     flt = fx.LowPass(); flt.input = o; flt.cutoff = fix(g['c2/cutoff'])
     mx = fx.Mix(); mx.left = flt; mx.right = o; mx.mix = fix([[0.5]])
     timer = KernelTimer()
     got = BatchRenderer(mx, 32, RATE, timer=timer, fuse=True).render(0, 256, 2).cpu().numpy()
     torch.cuda.synchronize()
-    assert not any(k.startswith('fused') for k in timer.summary())
+    assert set(timer.summary()) == {'voice_program[Osc,Save,Filter,Save,Load,Mix]'}, set(timer.summary())
+    assert maxerr(got, stream(mx, 0, 256, 2, 32)) < 3e-7
+    timer = KernelTimer()
+    got = BatchRenderer(mx, 32, RATE, timer=timer, fuse=True, fuse_program=False).render(0, 256, 2).cpu().numpy()
+    torch.cuda.synchronize()
+    assert not any(k.startswith(('fused', 'voice_program')) for k in timer.summary())
     assert np.array_equal(got, stream(mx, 0, 256, 2, 32))
 
 
@@ -507,10 +513,16 @@ def test_fused_first_stage_of_a_cascade(golden):
         f2 = fx.LowPass(); f2.input = f1; f2.cutoff = fix(c['casc/cut2'])
         return f2
     timer = KernelTimer()
-    r = BatchRenderer(build(), 8, RATE, timer=timer)
+    r = BatchRenderer(build(), 8, RATE, timer=timer, fuse_program=False)       # (by default the cascade is ONE interpreted launch, below)
     got = torch.cat([r.render(0, 256, 1), r.render(256, 256, 2), r.render(768, 256, 1)]).cpu().numpy()
     torch.cuda.synchronize()
     assert set(timer.summary()) == {'fused_osc_biquad[Sawtooth,lp]', 'biquad_coldstart[lp]'}
+    assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
+    timer = KernelTimer()
+    r = BatchRenderer(build(), 8, RATE, timer=timer)
+    got = torch.cat([r.render(0, 256, 1), r.render(256, 256, 2), r.render(768, 256, 1)]).cpu().numpy()
+    torch.cuda.synchronize()
+    assert set(timer.summary()) == {'voice_program[Osc,Filter,Filter]'}, set(timer.summary())
     assert maxerr(got, f32(c['casc/seq_n256'])) < 3e-7
     assert maxerr(batched(build(), 768, 256, 1, 8, fuse=True), batched(build(), 768, 256, 1, 8)) < 3e-7     # fresh start
 
@@ -537,10 +549,15 @@ def test_gain_folded_into_bus_weights(golden):
     for stereo in (False, True):
         C = 2 if stereo else 1
         timer = KernelTimer()
-        got = BatchRenderer(build(stereo), C, RATE, timer=timer).render(0, 256, 4).cpu().numpy()
+        got = BatchRenderer(build(stereo), C, RATE, timer=timer, fuse_program=False).render(0, 256, 4).cpu().numpy()
         torch.cuda.synchronize()
         assert 'elementwise[Gain]' not in timer.summary() and 'sum_bus' in timer.summary()
         assert maxerr(got, batched(build(stereo), 0, 256, 4, C)) < 1e-7
+        timer = KernelTimer()                                 # by default: the voice and the bus in one interpreted launch, the gain in the bus weights
+        one = BatchRenderer(build(stereo), C, RATE, timer=timer).render(0, 256, 4).cpu().numpy()
+        torch.cuda.synchronize()
+        assert set(timer.summary()) == {'voice_program_bus[Osc,Filter,Filter,Save,Osc,Mul]'}, set(timer.summary())
+        assert maxerr(one, got) < 1e-6 * max(1.0, float(np.abs(got).max()))
 
 
 def test_hipgraph_replay_of_the_latency_loop(golden):
@@ -585,7 +602,8 @@ def test_hipgraph_replay_of_the_latency_loop(golden):
 
 
 def test_ringmod_with_adsr_in_one_pass():
-    """SumBus(RingMod(Filter, ADSR)) -> one pass over the filter's input, nothing per-voice stored
+    """The schedules of earlier rounds, kept behind fuse_program=False (the default runs these graphs as one interpreted launch):
+    SumBus(RingMod(Filter, ADSR)) -> one pass over the filter's input, nothing per-voice stored
     (sig_biquad_coldstart_bus) when nothing else reads the three nodes; RingMod(Filter, ADSR) read by something
     else -> envelope in the filter's epilogue (sig_biquad_coldstart_env); filter read twice -> sig_adsr_apply; C3
     stays within 1e-6 of the oracle every way"""
@@ -597,8 +615,8 @@ def test_ringmod_with_adsr_in_one_pass():
 
     bus, p = c3_graph(V)
     timer = KernelTimer()
-    r = BatchRenderer(bus, 1, RATE, timer=timer)
-    r.fuse_cascade = False                       # (by default the whole voice is ONE launch: tests/test_gpu_fused_cascade.py)
+    r = BatchRenderer(bus, 1, RATE, timer=timer, fuse_program=False)
+    r.fuse_cascade = False                       # (by default the whole voice is ONE launch: tests/test_gpu_fused_cascade.py; without the cascade kernel one interpreted launch: tests/test_gpu_program_engine.py)
     got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
     torch.cuda.synchronize()
     names = set(timer.summary())
@@ -612,7 +630,7 @@ def test_ringmod_with_adsr_in_one_pass():
     # the RingMod itself is the sink: its rows must exist, the envelope goes into the filter's epilogue
     bus, p = c3_graph(V)
     timer = KernelTimer()
-    r = BatchRenderer(bus.input.sig, V, RATE, timer=timer)
+    r = BatchRenderer(bus.input.sig, V, RATE, timer=timer, fuse_program=False)
     got = np.concatenate([r.render(0, N, K).cpu().numpy(), r.render(N * K, N, K).cpu().numpy()])
     torch.cuda.synchronize()
     names = set(timer.summary())
@@ -633,7 +651,7 @@ def test_ringmod_with_adsr_in_one_pass():
         if stereo:
             b.get_state().gains = pan
         timer = KernelTimer()
-        rb = BatchRenderer(b, 2 if stereo else 1, RATE, timer=timer)
+        rb = BatchRenderer(b, 2 if stereo else 1, RATE, timer=timer, fuse_program=False)
         rb.fuse_cascade = False
         got = rb.render(0, N, K).cpu().numpy()
         torch.cuda.synchronize()
@@ -649,7 +667,7 @@ def test_ringmod_with_adsr_in_one_pass():
     rm = bus.input.sig
     both = fx_mix(rm, rm.left.sig)
     timer = KernelTimer()
-    got = BatchRenderer(both, V, RATE, timer=timer).render(0, N, K).cpu().numpy()
+    got = BatchRenderer(both, V, RATE, timer=timer, fuse_program=False).render(0, N, K).cpu().numpy()
     torch.cuda.synchronize()
     names = set(timer.summary())
     assert 'adsr_apply' in names and 'biquad_coldstart[lp,env]' not in names, names

@@ -64,9 +64,9 @@ def oracle_stream(p, pos, N, K, V, **kw):
     return R.sum_bus(R.render_stream(node, pos, N, K, V), pan)
 
 
-def fused(node, channels, timer=None):
+def fused(node, channels, timer=None, **kw):
     from signals_amd.engine import BatchRenderer
-    return BatchRenderer(node, channels, RATE, timer=timer)
+    return BatchRenderer(node, channels, RATE, timer=timer, **kw)
 
 
 def test_c3_graph_is_one_launch_and_matches_the_oracle():
@@ -245,19 +245,21 @@ def test_bad_cutoff_in_either_filter_is_reported():
 
 
 def test_block_sizes_the_cascade_kernel_does_not_take_fall_back_to_the_older_schedule():
-    """N must be a whole number of row groups (16 / bus channels) and > 100: otherwise the engine keeps its two-launch
-    schedule (fused Saw + LowPass, then filter + envelope + bus), same values within the float32 roundings between them"""
+    """N must be a whole number of row groups (16 / bus channels) and > 100: otherwise the voice runs as one interpreted
+    launch (sig_voice_program), or -- without it -- the two-launch schedule of round 1 (fused Saw + LowPass, then filter +
+    envelope + bus); the oracle's stream either way"""
     from signals_amd.engine import KernelTimer
     V, K = 24, 3
     p = params(V, 31)
     for N in (1000, 250):
-        timer = KernelTimer()
-        got = fused(graph(p), 1, timer).render(0, N, K).cpu().numpy()
-        torch.cuda.synchronize()
-        names = set(timer.summary())
-        assert not any(n.startswith('fused_cascade_bus') for n in names) and any(n.startswith('biquad_bus') for n in names), names
         ref = oracle_stream(p, 0, N, K, V)
-        assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), N
+        for program, prefix in ((True, 'voice_program_bus'), (False, 'biquad_bus')):
+            timer = KernelTimer()
+            got = fused(graph(p), 1, timer, fuse_program=program).render(0, N, K).cpu().numpy()
+            torch.cuda.synchronize()
+            names = set(timer.summary())
+            assert not any(n.startswith('fused_cascade_bus') for n in names) and any(n.startswith(prefix) for n in names), names
+            assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), (N, program)
 
 
 def test_a_stream_may_switch_between_the_per_node_schedule_and_the_cascade_kernel():
@@ -270,7 +272,7 @@ def test_a_stream_may_switch_between_the_per_node_schedule_and_the_cascade_kerne
     ref = oracle_stream(p, 0, N, 6, V)
     scale = max(1.0, np.abs(ref).max())
     timer = KernelTimer()
-    r = fused(graph(p), 1, timer)
+    r = fused(graph(p), 1, timer, fuse_program=False)
     r.fuse_cascade = False
     a = r.render(0, N, 2).cpu().numpy()                       # per-node: fused Saw + LowPass, then filter + envelope + bus
     r.fuse_cascade = True
@@ -302,20 +304,24 @@ def test_a_cascade_batch_followed_by_a_batch_the_kernel_does_not_take():
     ref = R.sum_bus(np.concatenate([R.render_stream(node, 0, N, 3, V), R.render_stream(node, 3 * N, 250, 2, V)]))
     scale = max(1.0, np.abs(ref).max())
     timer = KernelTimer()
-    r = fused(graph(p), 1, timer)
+    r = fused(graph(p), 1, timer, fuse_program=False)
     a = r.render(0, N, 3).cpu().numpy()                       # the cascade kernel
     torch.cuda.synchronize()
     assert set(timer.summary()) == {'fused_cascade_bus[Sawtooth,lp,lp,env]'}
     timer.reset()
     b = r.render(3 * N, 250, 2).cpu().numpy()                 # 250 frames: not a whole number of 16-row groups -> per node
     torch.cuda.synchronize()
-    assert not any(n.startswith('fused_cascade_bus') for n in timer.summary())
+    assert not any(n.startswith(('fused_cascade_bus', 'voice_program')) for n in timer.summary())
     assert maxerr(np.concatenate([a, b]), f32(ref)) < 1e-6 * scale
     fresh = fused(graph(p), 1).render(3 * N, 250, 2).cpu().numpy()
     assert maxerr(fresh, b) > 1e-5 * scale                    # ... which a fresh start at 3 N does NOT render
+    # by default the 250-frame batch is one interpreted launch, which re-walks the previous block itself: the same stream
+    rd = fused(graph(p), 1)
+    d = np.concatenate([rd.render(0, N, 3).cpu().numpy(), rd.render(3 * N, 250, 2).cpu().numpy()])
+    assert maxerr(d, f32(ref)) < 1e-6 * scale
     # the same with the kernel switched off mid-stream, and back on: every batch the oracle's sequential stream
     ref2 = R.sum_bus(R.render_stream(oracle(p)[0], 0, N, 7, V))
-    r2 = fused(graph(p), 1)
+    r2 = fused(graph(p), 1, fuse_program=False)
     parts = [r2.render(0, N, 2)]
     r2.fuse_cascade = False
     parts.append(r2.render(2 * N, N, 2))

@@ -85,11 +85,11 @@ def test_patches_render_like_the_reference(golden):
     torch.cuda.synchronize()
     assert set(timer.summary()) == {'fused_osc_biquad[Triangle,lp,gain]'}, set(timer.summary())
     assert np.array_equal(again, out)
-    # the patch's Merge reads the Gain too (4b -> 5a.left, 3a -> 5a.right): its rows then come from the per-node schedule
+    # the patch's Merge reads the Gain too (4b -> 5a.left, 3a -> 5a.right): its rows are a launch of their own (Osc x Gain as one voice program)
     timer = KernelTimer()
     both = BatchRenderer(patch['5a'], 2, 48000, timer=timer).render(0, 256, 3).cpu().numpy()
     torch.cuda.synchronize()
-    assert 'fused_osc_biquad[Triangle,lp,gain]' in set(timer.summary()) and 'elementwise[Gain]' in set(timer.summary())
+    assert set(timer.summary()) == {'fused_osc_biquad[Triangle,lp,gain]', 'voice_program[Osc,Gain]'}, set(timer.summary())
     assert np.max(np.abs(both - f32(g['sigs/lowpass_test']))) < 2e-7
 
 
