@@ -44,6 +44,12 @@ using sig_biquad::Biquad;
 using sig_bus::kTileStride;
 
 constexpr int kMaxIns = SIG_VP_MAX_INS;
+#ifndef SIG_VP_ROWS
+#define SIG_VP_ROWS 8
+#endif
+constexpr int kRowGroup = SIG_VP_ROWS;     // the interpreter runs every instruction for this many consecutive rows at a time: its dispatch
+                                           // (fetch, decode, two scalar switches) is paid once per group, and a handler has rows x voices
+                                           // independent evaluations to overlap
 
 struct Rows { const double* ptr; int cs; int rows; };      // (rows, V | 1) float64: rows == 1 holds for every block
 
@@ -62,12 +68,30 @@ struct VpArgs {
     int* status;
 };
 
-// f(integral_constant<int, i>) for a wave-uniform i < N: a scalar compare chain, so arrays indexed inside stay in registers
+// f(integral_constant<int, i>) for a wave-uniform i < N: a scalar switch, so arrays indexed inside stay in registers
 template <int N, typename F>
 __device__ __forceinline__ void with_index(int i, F&& f) {
-#define SIG_VP_CASE(k) if constexpr (N > k) { if (i == k) { asm volatile(""); f(std::integral_constant<int, k>{}); return; } }
-    SIG_VP_CASE(0) SIG_VP_CASE(1) SIG_VP_CASE(2) SIG_VP_CASE(3) SIG_VP_CASE(4) SIG_VP_CASE(5) SIG_VP_CASE(6) SIG_VP_CASE(7)
-#undef SIG_VP_CASE
+    switch (i) {
+        case 0: if constexpr (N > 0) f(std::integral_constant<int, 0>{}); break;
+        case 1: if constexpr (N > 1) f(std::integral_constant<int, 1>{}); break;
+        case 2: if constexpr (N > 2) f(std::integral_constant<int, 2>{}); break;
+        case 3: if constexpr (N > 3) f(std::integral_constant<int, 3>{}); break;
+        case 4: if constexpr (N > 4) f(std::integral_constant<int, 4>{}); break;
+        case 5: if constexpr (N > 5) f(std::integral_constant<int, 5>{}); break;
+        case 6: if constexpr (N > 6) f(std::integral_constant<int, 6>{}); break;
+        case 7: if constexpr (N > 7) f(std::integral_constant<int, 7>{}); break;
+        default: break;
+    }
+}
+
+// An opaque copy of a wave-uniform double.  A handler's arithmetic on the row's n / rate and the slot's block-invariant
+// registers does not depend on the instruction counter, so the optimiser hoists it out of the instruction loop and evaluates
+// EVERY case of every slot once per row, unconditionally (measured: all four waveforms of all oscillator slots per row, ~10x
+// the work of the program itself and twice the registers).  Passing an input through an empty volatile asm pins the work to
+// the case that needs it.
+__device__ __forceinline__ double vp_pin(double x) {
+    asm volatile("" : "+s"(x));
+    return x;
 }
 
 __device__ __forceinline__ uint64_t vp_mix64(uint64_t z) {                     // noise.hip
@@ -106,11 +130,11 @@ __device__ __forceinline__ void vp_put(float& v, const float (&y)[1]) { v = y[0]
 __device__ __forceinline__ void vp_put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
 
 // Register-file sizes per variant (the host picks the smallest variant a program fits).  SMALL: two filter slots, three
-// oscillator slots, four parameter registers, two temporaries, no Amp / ADSR / White -- the common synthesiser voice; its
+// oscillator slots, four parameter registers, one temporary (a temporary is a whole row group: 8 rows x 2 voices = 32 VGPRs), no Amp / ADSR / White -- the common synthesiser voice; its
 // state fits two waves per SIMD at two voices per lane, which the interpreter's scalar dispatch needs to hide its branches.
 // The full register file (four filters, four oscillators, eight parameters, four temporaries, every instruction) runs at one.
 template <bool SMALL> struct VpLimits {
-    static constexpr int NF = SMALL ? 2 : 4, NO = SMALL ? 3 : 4, NP = SMALL ? 4 : 8, NT = SMALL ? 2 : 4;
+    static constexpr int NF = SMALL ? 2 : 4, NO = SMALL ? 3 : 4, NP = SMALL ? 4 : 8, NT = SMALL ? 1 : 4;
     static constexpr bool EXT = !SMALL;
 };
 
@@ -118,6 +142,7 @@ template <bool SMALL> struct VpLimits {
 template <int VPT, bool SMALL, int C>
 __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane, int wave)
 {
+    constexpr int RG = SMALL ? kRowGroup : kRowGroup / 2;                      // rows per instruction dispatch (the full register file: four temporaries of a row group each)
     constexpr bool BUS = C > 0;
     constexpr int CC = BUS ? C : 1;
     using L = VpLimits<SMALL>;
@@ -139,7 +164,7 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #pragma unroll
     for (int k = 0; k < kMaxIns; ++k) codev = (lane == k) ? a.code[k] : codev;
 
-    double acc[VPT], T[NT][VPT], pr[NP][VPT], ohz[NO][VPT], oph[NO][VPT];
+    double acc[RG][VPT], T[NT][RG][VPT], pr[NP][VPT], ohz[NO][VPT], oph[NO][VPT];
     double z0[NF][VPT], z1[NF][VPT], w0[NF][VPT], w1[NF][VPT], na1[NF][VPT], na2[NF][VPT], fb0[NF][VPT], xa1[NF][VPT], xa2[NF][VPT];
     double s2[NF];
     double wt[CC][VPT];
@@ -152,10 +177,13 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #pragma unroll
     for (int k = 0; k < NT; ++k)
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) T[k][i] = 0.0;
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) T[k][r][i] = 0.0;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        acc[i] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) acc[r][i] = 0.0;
 #pragma unroll
         for (int ch = 0; ch < CC; ++ch) wt[ch][i] = BUS ? ((v0 + i < a.voices) ? (a.pan ? a.pan[ch * a.pan_ld + voice(i)] : 1.0) : 0.0) : 1.0;
     }
@@ -242,39 +270,37 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
     // next block's chains] then rows [from, to).  One loop, so that the row interpreter exists once in the code.
     const int D = a.depth, H = a.hist;
     const int ctx = (D > 0) ? a.ctx : 0;                                       // no filter: no context rows at all
-    struct Step { bool load, enter, next, warm, out; int next_level; int64_t cri_load, cri_enter, cri_next, from, to; };
+    // `warm_from`: the row from which the NEXT block's chains run too (their zero state and design are set up when the walk gets
+    // there); == to: none in this step
+    struct Step { bool load, enter, out, next0; int next_level; int64_t cri_load, cri_enter, cri_next, from, to, warm_from; };   // next0: the next chains start with the step, even an empty one
     auto bpos = [&](int64_t j) -> int64_t { return j >= 0 ? a.position + j * (int64_t)a.N : a.hist_pos[H + j]; };   // j >= -H
     auto cri = [&](int64_t j) -> int64_t { return j + H + 1; };                // control rows: [one in front | H blocks in front | K blocks]
     int64_t j0 = b_first - (D > 1 ? D - 1 : 0);
     if (j0 < -(int64_t)H) j0 = -(int64_t)H;
     const int64_t j_end = b_first + nb;
     int n_steps;
-    if (!a.small) n_steps = 1 + 2 * (int)(j_end - j0);
+    if (!a.small) n_steps = 1 + (int)(j_end - j0);
     else n_steps = (D >= 2) ? 4 : 2;
     auto make_step = [&](int t) {
-        Step st{false, false, false, false, false, 0, 0, 0, 0, 0, 0};
+        Step st{false, false, false, false, 0, 0, 0, 0, 0, 0, 0};
         if (!a.small) {
             if (t == 0) {                                                      // the rows in front of the first block belong to the block before it
                 const int64_t s0 = bpos(j0);
                 const int64_t c0 = (s0 < (int64_t)ctx) ? s0 : (int64_t)ctx;
                 st.load = true; st.cri_load = cri(j0) - 1;
-                st.next = true; st.cri_next = cri(j0);
-                st.from = s0 - c0; st.to = s0; st.warm = true;
+                st.cri_next = cri(j0); st.next0 = true;
+                st.from = s0 - c0; st.to = s0; st.warm_from = st.from;
                 return st;
             }
-            const int64_t j = j0 + (t - 1) / 2;
-            const int64_t s = bpos(j), e = bpos(j + 1);
+            const int64_t j = j0 + (t - 1);
+            const int64_t s0 = bpos(j), e = bpos(j + 1);
             int64_t cn = (j + 1 < j_end) ? ((e < (int64_t)ctx) ? e : (int64_t)ctx) : 0;     // the next block's context, inside this one
-            if (cn > e - s) cn = e - s;
+            if (cn > e - s0) cn = e - s0;
             st.out = j >= b_first;
-            if ((t - 1) % 2 == 0) {
-                st.enter = true; st.cri_enter = cri(j);
-                st.load = true; st.cri_load = cri(j);
-                st.from = s; st.to = e - cn;
-            } else {
-                st.next = cn > 0; st.cri_next = cri(j + 1);
-                st.from = e - cn; st.to = e; st.warm = true;
-            }
+            st.enter = true; st.cri_enter = cri(j);
+            st.load = true; st.cri_load = cri(j);
+            st.cri_next = cri(j + 1);
+            st.from = s0; st.to = e; st.warm_from = e - cn;
             return st;
         }
         // Blocks shorter than the context: every block behind its own virtual block [vp, p), vp = max(p - ctx, 0), whose
@@ -288,12 +314,12 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
         if (D < 2) {
             if (t == 0) {                                                      // the virtual block: the whole of it is the block's context
                 st.load = true; st.cri_load = b_first;
-                st.next = true; st.cri_next = a.K + b_first;
-                st.from = vp; st.to = p; st.warm = true;
+                st.cri_next = a.K + b_first; st.next0 = true;
+                st.from = vp; st.to = p; st.warm_from = vp;
             } else {
                 st.enter = true; st.cri_enter = a.K + b_first;
                 st.load = true; st.cri_load = a.K + b_first;
-                st.from = p; st.to = p + a.N; st.out = true;
+                st.from = p; st.to = p + a.N; st.warm_from = st.to; st.out = true;
             }
             return st;
         }
@@ -304,171 +330,274 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
         const int64_t q = p - m * a.N;
         const int64_t qc = q - ((q < (int64_t)ctx) ? q : (int64_t)ctx);        // where the inner filter of the block's own rows cold-starts
         const int64_t c0 = (vp < (int64_t)ctx) ? vp : (int64_t)ctx;
-        int64_t r0 = vp - c0;                                                  // ... and where the virtual block's inner filter does
-        int64_t r1 = (qc < r0) ? r0 : ((qc > vp) ? vp : qc);
+        const int64_t r0 = vp - c0;                                            // ... and where the virtual block's inner filter does
+        const int64_t r1 = (qc < r0) ? r0 : ((qc > vp) ? vp : qc);
         if (t == 0) {                                                          // the virtual block's inner filter alone (current chains from zero)
             st.enter = true; st.cri_enter = b_first;
             st.load = true; st.cri_load = b_first;
-            st.from = r0; st.to = r1;
+            st.from = r0; st.to = r1; st.warm_from = r1;
         } else if (t == 1) {                                                   // + the inner filter of the block's own rows warms up
-            st.next = true; st.next_level = 1; st.cri_next = a.K + b_first;
-            st.from = r1; st.to = vp; st.warm = true;
+            st.next_level = 1; st.cri_next = a.K + b_first; st.next0 = true;
+            st.from = r1; st.to = vp; st.warm_from = r1;
         } else if (t == 2) {                                                   // the virtual block: the outer filter cold-starts on it
-            st.next = true; st.next_level = 2; st.cri_next = a.K + b_first;
-            st.from = vp; st.to = p; st.warm = true;
+            st.next_level = 2; st.cri_next = a.K + b_first; st.next0 = true;
+            st.from = vp; st.to = p; st.warm_from = vp;
         } else {
             st.enter = true; st.cri_enter = a.K + b_first;
             st.load = true; st.cri_load = a.K + b_first;
-            st.from = p; st.to = p + a.N; st.out = true;
+            st.from = p; st.to = p + a.N; st.warm_from = st.to; st.out = true;
         }
         return st;
     };
 
-    // rows [from, to): every instruction of the program per row; WARM rows also advance the next block's chains
+    // rows [from, to): every instruction of the program for a group of R consecutive rows at a time (R = RG, then single rows
+    // for what is left of the segment); WARM rows also advance the next block's chains
     double q_lane = 0.0;
     int64_t qbase = 0;
     bool q_valid = false;
-    for (int t = 0; t < n_steps; ++t) {
-        const Step st = make_step(t);
-        if (st.load) load_params(st.cri_load);
-        if (st.enter) enter_block(st.cri_enter);
-        if (st.next) start_next(st.cri_next, st.next_level);
-        const int64_t from = st.from, to = st.to;
-        const bool warm = st.warm, out = st.out;
-        if (from >= to) continue;
-        seed_envelope((double)from / a.rate);
-        for (int64_t n = from; n < to; ++n) {
-            if (!q_valid || n < qbase || n >= qbase + SIG_WAVE) {              // n / rate (IEEE divide) for 64 rows at a time, one per lane
-                qbase = n;
-                q_lane = (double)(qbase + lane) / a.rate;
-                q_valid = true;
-            }
-            const double q = sig_readlane_f64(q_lane, (int)(n - qbase));       // osc.py:32
-            for (int pc = 0; pc < a.n_ins; ++pc) {
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codev, pc);
-                const int op = (int)(w & 31u), kind = (int)((w >> 5) & 7u), ia = (int)((w >> 8) & 15u), ib = (int)((w >> 12) & 15u),
-                          ic = (int)((w >> 16) & 15u);
-                if (op == SIG_VP_OSC) {
+    sig_bus::FoldedGroup<CC> folded(tile, lane, dstp);                         // whole groups of the bus sink: sums folded across lanes in registers
+    auto group = [&](int64_t n, int warm_r, bool out, auto rows_tag) {        // warm_r: the first row of the group that also advances the next chains (R: none)
+        constexpr int R = decltype(rows_tag)::value;
+        if (!q_valid || n < qbase || n + R > qbase + SIG_WAVE) {                // n / rate (IEEE divide) for 64 rows at a time, one per lane
+            qbase = n;
+            q_lane = (double)(qbase + lane) / a.rate;
+            q_valid = true;
+        }
+        double q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = sig_readlane_f64(q_lane, (int)(n - qbase) + r);     // osc.py:32
+        for (int pc = 0; pc < a.n_ins; ++pc) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codev, pc);
+            const int op = (int)(w & 31u), kind = (int)((w >> 5) & 7u), ia = (int)((w >> 8) & 15u), ib = (int)((w >> 12) & 15u),
+                      ic = (int)((w >> 16) & 15u);
+            switch (op) {
+                case SIG_VP_OSC:
                     with_index<NO>(ia, [&](auto I) {
                         constexpr int S = decltype(I)::value;
-                        double t[VPT];
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) t[i] = q * ohz[S][i] + oph[S][i];
-                        if (kind == SIG_OSC_SINE) {
-    #pragma unroll
-                            for (int i = 0; i < VPT; ++i) acc[i] = (double)sig_osc::osc_sine_f32(t[i]);
-                        } else if (kind == SIG_OSC_SAWTOOTH) {
-    #pragma unroll
-                            for (int i = 0; i < VPT; ++i) acc[i] = sig_osc::osc_sawtooth_fract(t[i]);
-                        } else if (kind == SIG_OSC_SQUARE) {
-    #pragma unroll
-                            for (int i = 0; i < VPT; ++i) acc[i] = sig_osc::osc_square_fract(t[i]);
-                        } else {
-    #pragma unroll
-                            for (int i = 0; i < VPT; ++i) acc[i] = sig_osc::osc_triangle_fract(t[i]);
+                        double t[R][VPT];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const double qr = vp_pin(q[r]);
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) t[r][i] = qr * ohz[S][i] + oph[S][i];
+                        }
+                        switch (kind) {
+                            case SIG_OSC_SINE:
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) acc[r][i] = (double)sig_osc::osc_sine_f32(t[r][i]);
+                                break;
+                            case SIG_OSC_SAWTOOTH:
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) acc[r][i] = sig_osc::osc_sawtooth_fract(t[r][i]);
+                                break;
+                            case SIG_OSC_SQUARE:
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) acc[r][i] = sig_osc::osc_square_fract(t[r][i]);
+                                break;
+                            default:
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) acc[r][i] = sig_osc::osc_triangle_fract(t[r][i]);
+                                break;
                         }
                     });
-                } else if (op == SIG_VP_FILTER) {
+                    break;
+                case SIG_VP_FILTER:
                     with_index<NF>(ia, [&](auto I) {
                         constexpr int F = decltype(I)::value;
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) {
-                            const double x = acc[i];
-                            const double y = x + z0[F][i];                     // DF2T of [1, s2, 1] / [1, a1, a2]
-                            z0[F][i] = fma(na1[F][i], y, fma(s2[F], x, z1[F][i]));
-                            z1[F][i] = fma(na2[F][i], y, x);
-                            if (warm) {                                        // wave-uniform: the next block's chain on the same input
-                                asm volatile("");
-                                const double yw = x + w0[F][i];
-                                w0[F][i] = fma(xa1[F][i], yw, fma(s2[F], x, w1[F][i]));
-                                w1[F][i] = fma(xa2[F][i], yw, x);
+                        if (warm_r < R) {                                      // wave-uniform: the next block's chain, on the same input rows
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (r >= warm_r) {                             // (wave-uniform too: a group may straddle the first warm row)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) {
+                                        const double x = acc[r][i];
+                                        const double yw = x + w0[F][i];
+                                        w0[F][i] = fma(xa1[F][i], yw, fma(s2[F], x, w1[F][i]));
+                                        w1[F][i] = fma(xa2[F][i], yw, x);
+                                    }
+                                }
                             }
-                            acc[i] = fb0[F][i] * y;
+                        }
+#pragma unroll
+                        for (int i = 0; i < VPT; ++i) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const double x = acc[r][i];
+                                const double y = x + z0[F][i];                 // DF2T of [1, s2, 1] / [1, a1, a2]
+                                z0[F][i] = fma(na1[F][i], y, fma(s2[F], x, z1[F][i]));
+                                z1[F][i] = fma(na2[F][i], y, x);
+                                acc[r][i] = fb0[F][i] * y;
+                            }
                         }
                     });
-                } else if (op == SIG_VP_GAIN) {
+                    break;
+                case SIG_VP_GAIN:
                     with_index<NP>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) acc[i] = acc[i] * pr[decltype(I)::value][i];        // fx.py:52
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) acc[r][i] = acc[r][i] * pr[decltype(I)::value][i];      // fx.py:52
                     });
-                } else if (op == SIG_VP_MUL) {
+                    break;
+                case SIG_VP_MUL:
                     with_index<NT>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) acc[i] = T[decltype(I)::value][i] * acc[i];         // fx.py:46
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) acc[r][i] = T[decltype(I)::value][r][i] * acc[r][i];     // fx.py:46
                     });
-                } else if (op == SIG_VP_SAVE) {
+                    break;
+                case SIG_VP_SAVE:
                     with_index<NT>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) T[decltype(I)::value][i] = acc[i];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) T[decltype(I)::value][r][i] = acc[r][i];
                     });
-                } else if (op == SIG_VP_LOAD) {
+                    break;
+                case SIG_VP_LOAD:
                     with_index<NT>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) acc[i] = T[decltype(I)::value][i];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) acc[r][i] = T[decltype(I)::value][r][i];
                     });
-                } else if (op == SIG_VP_MIX) {                                 // m * L + (1 - m) * R (fx.py:40); ic: the accumulator is L
+                    break;
+                case SIG_VP_MIX: {                                             // m * L + (1 - m) * R (fx.py:40); ic: the accumulator is L
                     double m[VPT];
                     with_index<NP>(ib, [&](auto I) {
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < VPT; ++i) m[i] = pr[decltype(I)::value][i];
                     });
                     with_index<NT>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) {
-                            const double l = ic ? acc[i] : T[decltype(I)::value][i], r = ic ? T[decltype(I)::value][i] : acc[i];
-                            acc[i] = m[i] * l + (1.0 - m[i]) * r;
-                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) {
+                                const double l = ic ? acc[r][i] : T[decltype(I)::value][r][i], rr = ic ? T[decltype(I)::value][r][i] : acc[r][i];
+                                acc[r][i] = m[i] * l + (1.0 - m[i]) * rr;
+                            }
                     });
-                } else if (op == SIG_VP_CONST) {
-                    with_index<NP>(ia, [&](auto I) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) acc[i] = pr[decltype(I)::value][i];
-                    });
-                } else if constexpr (EXT) {
-                    if (op == SIG_VP_AMP) {
-                        with_index<NP>(ia, [&](auto I) {
-    #pragma unroll
-                            for (int i = 0; i < VPT; ++i) acc[i] = vp_amp(acc[i], pr[decltype(I)::value][i]);
-                        });
-                    } else if (op == SIG_VP_ADSR) {
-                        bool stale = false;
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) stale |= !(q < seg[i].end);
-                        if (__any(stale)) seed_envelope(q);                    // a stage ended: at most five times per voice and stream
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) acc[i] = fma(seg[i].slope, q - seg[i].t0, seg[i].l0);
-                    } else if (op == SIG_VP_NOISE) {
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) {
-                            const int ch = v0 + i;
-                            const uint64_t h = vp_mix64(a.seeds[ia & 1] + (uint64_t)n * 0x9E3779B97F4A7C15ULL + (uint64_t)(ch >> 1) * 0xD1B54A32D192ED03ULL);
-                            const uint32_t k = ((ch & 1) ? (uint32_t)(h >> 32) : (uint32_t)h) >> 8;
-                            acc[i] = (double)((float)k * 5.9604644775390625e-8f);
-                        }
-                    }
+                    break;
                 }
-            }
-            if (out) {
-                if constexpr (BUS) {
-    #pragma unroll
-                    for (int ch = 0; ch < CC; ++ch) {
-                        double s = 0.0;
-    #pragma unroll
-                        for (int i = 0; i < VPT; ++i) s = fma(wt[ch][i], acc[i], s);
-                        stage.slot[ch * kTileStride] = s;
+                case SIG_VP_CONST:
+                    with_index<NP>(ia, [&](auto I) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) acc[r][i] = pr[decltype(I)::value][i];
+                    });
+                    break;
+                default:
+                    if constexpr (EXT) {
+                        if (op == SIG_VP_AMP) {
+                            with_index<NP>(ia, [&](auto I) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+#pragma unroll
+                                    for (int i = 0; i < VPT; ++i) acc[r][i] = vp_amp(acc[r][i], pr[decltype(I)::value][i]);
+                            });
+                        } else if (op == SIG_VP_ADSR) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const double qr = vp_pin(q[r]);
+                                bool stale = false;
+#pragma unroll
+                                for (int i = 0; i < VPT; ++i) stale |= !(qr < seg[i].end);
+                                if (__any(stale)) seed_envelope(qr);           // a stage ended: at most five times per voice and stream
+#pragma unroll
+                                for (int i = 0; i < VPT; ++i) acc[r][i] = fma(seg[i].slope, qr - seg[i].t0, seg[i].l0);
+                            }
+                        } else if (op == SIG_VP_NOISE) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int i = 0; i < VPT; ++i) {
+                                    const int ch = v0 + i;
+                                    const uint64_t h = vp_mix64(a.seeds[ia & 1] + (uint64_t)(n + r) * 0x9E3779B97F4A7C15ULL +
+                                                                (uint64_t)(ch >> 1) * 0xD1B54A32D192ED03ULL);
+                                    const uint32_t k = ((ch & 1) ? (uint32_t)(h >> 32) : (uint32_t)h) >> 8;
+                                    acc[r][i] = (double)((float)k * 5.9604644775390625e-8f);
+                                }
+                        }
                     }
-                    stage.advance();
-                } else {
-                    float y32[VPT];
-    #pragma unroll
-                    for (int i = 0; i < VPT; ++i) y32[i] = (float)acc[i];
-                    if (live0) {
-                        Vec o; vp_put(o, y32);
-                        *reinterpret_cast<Vec*>(dst + (n - a.position) * a.out_ld) = o;
+                    break;
+            }
+        }
+        if (out) {
+            if constexpr (BUS && (R * CC == 16 || R * CC == 8)) {
+                // a whole group of the bus: its R x C sums stay in registers, are folded across lanes four at a time (two
+                // register-to-register halving steps, sig_bus::FoldedGroup) and only a quarter goes through the LDS
+                if (stage.staged) stage.now();                                 // single rows staged before: out first, in order
+                double sums[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sums[k] = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int ch = 0; ch < CC; ++ch) {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int i = 0; i < VPT; ++i) sum = fma(wt[ch][i], acc[r][i], sum);
+                        sums[r * CC + ch] = sum;
+                    }
+#pragma unroll
+                for (int g4 = 0; g4 < (R * CC) / 4; ++g4) folded.fold4(g4, sums[4 * g4], sums[4 * g4 + 1], sums[4 * g4 + 2], sums[4 * g4 + 3]);
+                double pend[4];
+                folded.issue(pend);
+                folded.finish(pend, stage.first, R);
+                stage.first += R;
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if constexpr (BUS) {
+#pragma unroll
+                        for (int ch = 0; ch < CC; ++ch) {
+                            double sum = 0.0;
+#pragma unroll
+                            for (int i = 0; i < VPT; ++i) sum = fma(wt[ch][i], acc[r][i], sum);
+                            stage.slot[ch * kTileStride] = sum;
+                        }
+                        stage.advance();
+                    } else {
+                        float y32[VPT];
+#pragma unroll
+                        for (int i = 0; i < VPT; ++i) y32[i] = (float)acc[r][i];
+                        if (live0) {
+                            Vec o; vp_put(o, y32);
+                            *reinterpret_cast<Vec*>(dst + (n + r - a.position) * a.out_ld) = o;
+                        }
                     }
                 }
             }
         }
+    };
+    for (int t = 0; t < n_steps; ++t) {
+        const Step st = make_step(t);
+        if (st.load) load_params(st.cri_load);
+        if (st.enter) enter_block(st.cri_enter);
+        bool started = false;                                                  // the next chains of this step
+        if (st.next0) { start_next(st.cri_next, st.next_level); started = true; }
+        if (st.from >= st.to) continue;
+        seed_envelope((double)st.from / a.rate);
+        int64_t n = st.from;
+        auto warm_rows = [&](int64_t at, int rows) {                           // first warm row of the group at `at` (rows: none), chains started on arrival
+            if (st.warm_from >= at + rows) return rows;
+            if (!started) { start_next(st.cri_next, st.next_level); started = true; }
+            return (st.warm_from <= at) ? 0 : (int)(st.warm_from - at);
+        };
+        if constexpr (RG > 1) {
+            for (; n + RG <= st.to; n += RG) group(n, warm_rows(n, RG), st.out, std::integral_constant<int, RG>{});
+        }
+        for (; n < st.to; ++n) group(n, warm_rows(n, 1), st.out, std::integral_constant<int, 1>{});
     }
     if (BUS && stage.staged) stage.now();
 }
@@ -476,8 +605,11 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #ifndef SIG_VP_WAVES
 #define SIG_VP_WAVES 2
 #endif
+#ifndef SIG_VP_WAVES1
+#define SIG_VP_WAVES1 3
+#endif
 template <int VPT, bool SMALL, int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? SIG_VP_WAVES : 1, 8))) void voice_program_kernel(VpArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? (VPT == 1 ? SIG_VP_WAVES1 : SIG_VP_WAVES) : 1, 8))) void voice_program_kernel(VpArgs a)
 {
     constexpr bool BUS = C > 0;
     __shared__ double lds[BUS ? 4 : 1][BUS ? sig_bus::kPairs * kTileStride : 1];

@@ -159,7 +159,9 @@ class BatchRenderer:
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
         `fuse_program` (default: as `fuse`): graphs none of the fused kernels covers run as one interpreted launch per sink
-        (sig_voice_program) instead of one kernel per node.
+        (sig_voice_program) instead of one kernel per node -- where the interpreter beats that schedule (programs that fit its
+        small register file, and every block size below the filter context, which the per-node schedule cannot batch at all);
+        'always': wherever the graph compiles.
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -183,7 +185,9 @@ class BatchRenderer:
         self._tails_rebuilt = False                        # the previous block was re-rendered per node for this batch's tails
         self._recent_blocks: list[tuple[int, int]] = []    # (start, end) of the last few blocks of the contiguous stream rendered so far
         self._stream_blocks = 0                            # blocks of the CURRENT size rendered contiguously since the stream started
-        self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)   # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program)
+        # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program) -- True: where that beats
+        # one kernel per node (_VoiceProgram.worthwhile), 'always': wherever the graph compiles
+        self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -780,6 +784,8 @@ class _Batch:
         prog = _VoiceProgram.compile(self, node, channels)
         if prog is None or any(n in memo_keys for n in prog.uses if n is not node):
             return None                                                        # (an inner node already has rows in this batch: someone else reads it)
+        if self.owner.fuse_program != 'always' and not prog.worthwhile():
+            return None
         # the node's natural width: every control row is one column wide -> the reply is (rows, 1), broadcast by the consumer
         try:
             tensors = [c if c is not None else self._control_const(p, p.name) if _ctl_const(p) else None for p, c, _ in prog.controls]
@@ -805,6 +811,8 @@ class _Batch:
         memo_keys = {k[0] for k in self._memo}
         prog = _VoiceProgram.compile(self, src_port.sig, voices)
         if prog is None or any(n in memo_keys for n in prog.uses):
+            return None
+        if self.owner.fuse_program != 'always' and not prog.worthwhile():
             return None
         if len(src_port.sig.outputs_with_ports) != 1:
             return None                                                        # (the bus input has another reader: its rows must exist)
@@ -1626,14 +1634,24 @@ class _VoiceProgram:
             self.code.append(('Gain' if isinstance(n, fx.Gain) else 'Amp', 0, self._param(self._control(n.right, below)), 0, 0))
         elif isinstance(n, (fx.Mix, fx.RingMod)):
             left = self._emit(n.left.sig, below)
-            t = self._temp()
-            self.code.append(('Save', 0, t, 0, 0))
-            right = self._emit(n.right.sig, below)
+            kept = self.saved.get(n.right.sig) if n.right.sig is not n.left.sig else None
+            if kept is not None:
+                # the right operand is a node with several readers that already sits in a temporary: combine straight from it
+                t, right, swapped = kept[0], self.depth_of[n.right.sig], 1                    # (the accumulator is the LEFT operand)
+                kept[1] -= 1
+            else:
+                t, swapped = self._temp(), 0
+                self.code.append(('Save', 0, t, 0, 0))
+                right = self._emit(n.right.sig, below)
             if isinstance(n, fx.Mix):
-                self.code.append(('Mix', 0, t, self._param(self._control(n.mix, below)), 0))      # m T + (1 - m) acc  (fx.py:40)
+                self.code.append(('Mix', 0, t, self._param(self._control(n.mix, below)), swapped))     # m L + (1 - m) R  (fx.py:40)
             else:
                 self.code.append(('Mul', 0, t, 0, 0))
-            self.temps_free.append(t)
+            if kept is None:
+                self.temps_free.append(t)
+            elif kept[1] == 0:
+                self.temps_free.append(t)
+                del self.saved[n.right.sig]
             depth = max(left, right)
         elif isinstance(n, fx.SingleCritFilter):
             src = n.input.sig
@@ -1756,6 +1774,17 @@ class _VoiceProgram:
 
     def describe(self) -> str:
         return ','.join(op for op, *_ in self.code)
+
+    def worthwhile(self) -> bool:
+        """Does the interpreted launch beat one kernel per node?  Measured (tools/time_voice_program.py, 1024 voices): programs
+        that fit the interpreter's SMALL register file -- two filters, three oscillators, four parameter registers, one
+        temporary, no Amp / ADSR / White -- run at two waves per SIMD, 0.36-0.8 T voice-samples/s against 0.2-0.26 T per node;
+        the full register file runs at one wave per SIMD and loses (0.14 T for three filters in series; f64 pow dominates an
+        Amp either way).  Blocks shorter than the filter context have no per-node schedule at all (the alternative is the eager
+        pull path, ~150 us per block)."""
+        small_file = (len(self.filters) <= 2 and len(self.oscs) <= 3 and len(self.params) <= 4 and self.n_temps <= 1
+                      and self.adsr is None and not self.seeds and not any(op == 'Amp' for op, *_ in self.code))
+        return small_file or (self.depth > 0 and self.batch.N < CONTEXT)
 
 
 _KNOWN_TYPES = tuple(t for types, _ in _Batch._SCHEDULES for t in (types if isinstance(types, tuple) else (types,)))

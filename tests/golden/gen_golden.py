@@ -322,6 +322,80 @@ def gen_modulated(out):
                 [np.array(p.input.request(loc(start + b * N, N, V))) for b in range(blocks)])
 
 
+def gen_small_blocks(out):
+    """Blocks no longer than the filter context (dev.py:139-141: the sink takes whatever block size PortAudio hands it; 32- and
+    64-frame callbacks are the normal real-time case): two filters in series and a block-rate modulated voice rendered
+    sequentially in 32-, 50-, 64- and 100-frame blocks.  A filter's context request [p - 100, p) then lies in no single cached
+    block of its input and is answered as a block of its own, while the block itself is served from the OLDEST cached reply to
+    an `after` request that contains it (chain/__init__.py:431-442) -- what the engine's voice program reproduces.  Also three
+    filters in series at 256 frames (the block history reaches two blocks back)."""
+    V = 8
+    vp = voice_params(V, seed=3)
+    cut1 = np.geomspace(25, 4000, V).reshape(1, V)            # slow inner filters: where a chain was cold-started matters
+    cut2 = np.geomspace(300, 9000, V).reshape(1, V)
+    cut3 = np.geomspace(9000, 40, V).reshape(1, V)
+    gain = np.linspace(0.2, 1.0, V).reshape(1, V)
+    for k, v in (('hertz', vp['hertz']), ('phase', vp['phase']), ('cut1', cut1), ('cut2', cut2), ('cut3', cut3), ('gain', gain)):
+        out[f'small/{k}'] = v
+
+    def cascade(depth=2):
+        o = osc.Triangle()
+        o.hertz = fix(vp['hertz'])
+        o.phase = fix(vp['phase'])
+        f1 = fx.LowPass()
+        f1.input = o
+        f1.cutoff = fix(cut1)
+        f2 = fx.HighPass()
+        f2.input = f1
+        f2.cutoff = fix(cut2)
+        top = f2
+        if depth == 3:
+            f3 = fx.LowPass()
+            f3.input = f2
+            f3.cutoff = fix(cut3)
+            top = f3
+        g = fx.Gain()
+        g.left = top
+        g.right = fix(gain)
+        return g
+
+    def lfo(kind, hz, depth, centre):
+        o = OSC[kind]()
+        o.hertz = fix([[hz]])
+        m = fx.Mix()
+        m.left = o
+        m.right = fix([[1.0]])
+        m.mix = fix([[depth]])
+        r = fx.RingMod()
+        r.left = m
+        r.right = fix(centre)
+        return r
+
+    def fm_voice():
+        o = osc.Sawtooth()
+        o.hertz = lfo('Sine', 5.3, 0.02, vp['hertz'])
+        o.phase = lfo('Triangle', 2.1, 0.1, vp['phase'])
+        f = fx.LowPass()
+        f.input = o
+        f.cutoff = lfo('Sine', 1.7, 0.4, cut2)
+        g = fx.Gain()
+        g.left = f
+        g.right = lfo('Triangle', 3.1, 0.3, gain)
+        return g
+
+    for N in (32, 50, 64, 100):
+        for start in (0, 4096):
+            for name, build in (('cascade', cascade), ('fm', fm_voice)):
+                p = Probe()
+                p.input = build()
+                out[f'small/{name}/n{N}_p{start}'] = np.concatenate(
+                    [np.array(p.input.request(loc(start + b * N, N, V))) for b in range(12)])
+    p = Probe()
+    p.input = cascade(3)
+    out['small/cascade3/n256_p0'] = np.concatenate([np.array(p.input.request(loc(b * 256, 256, V))) for b in range(6)])
+    out['small/cascade3/fresh_p1000'] = render(cascade(3), 1000, 256, V)
+
+
 def gen_pairs(out):
     """A filter reading TWO oscillators through Mix / RingMod (fx.py:35-46), and a Gain in front of a filter: the
     topologies round 2's fuser folds into one launch; rendered sequentially."""
@@ -493,6 +567,7 @@ def main():
     groups = {
         'osc': gen_osc, 'filter': gen_filter, 'cascade': gen_cascade, 'effects': gen_effects,
         'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc, 'modulated': gen_modulated, 'pairs': gen_pairs,
+        'small': gen_small_blocks,
     }
     meta = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                 rate=RATE, reference='/root/reference (noah-aviel-dove/signals @ v1)',

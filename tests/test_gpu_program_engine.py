@@ -114,7 +114,7 @@ def test_shapes_beyond_the_fused_kernels_are_one_launch_and_match_the_oracle(whi
     ref = R.render_stream(ref_node, 0, N, sum(batches), V)
     scale = max(1.0, np.nanmax(np.abs(ref)))
     timer = KernelTimer()
-    got = render_batches(node, V, 0, N, batches, timer)
+    got = render_batches(node, V, 0, N, batches, timer, fuse_program='always')     # (by default only where it beats one kernel per node)
     names = launches(timer)
     assert len([n for n in names if n.startswith('voice_program[')]) == 1, names
     assert all(n.startswith(('voice_program[', 'control_program')) for n in names), names
@@ -123,7 +123,7 @@ def test_shapes_beyond_the_fused_kernels_are_one_launch_and_match_the_oracle(whi
     node, ref_node = shapes(p, which)
     bus = ext.SumBus(); bus.input = node; bus.get_state().gains = np.ascontiguousarray(p['pan'])
     timer = KernelTimer()
-    got = render_batches(bus, 2, 0, N, batches, timer)
+    got = render_batches(bus, 2, 0, N, batches, timer, fuse_program='always')
     names = launches(timer)
     assert any(n.startswith('voice_program_bus[') for n in names) and not any(n.startswith(('sum_bus', 'biquad', 'osc_bank')) for n in names), names
     want = np.nan_to_num(R.render_stream(ref_node, 0, N, sum(batches), V)) @ p['pan'].T if which == 'amp_after_filter' else ref @ p['pan'].T
@@ -132,8 +132,16 @@ def test_shapes_beyond_the_fused_kernels_are_one_launch_and_match_the_oracle(whi
     # a fresh renderer mid-stream answers what a fresh reference graph answers
     node, ref_node = shapes(p, which)
     fresh_ref = R.render_stream(ref_node, 5 * N, N, 2, V)
-    fresh = render_batches(node, V, 5 * N, N, (2,))
+    fresh = render_batches(node, V, 5 * N, N, (2,), fuse_program='always')
     assert maxerr(fresh, f32(fresh_ref)) < 1e-6 * scale, which
+    # the default policy: the interpreter where it beats one kernel per node (programs that fit its small register file)
+    node, _ = shapes(p, which)
+    timer = KernelTimer()
+    default = render_batches(node, V, 0, N, batches, timer)
+    small = which not in ('amp_after_filter', 'three_filters')
+    if which != 'three_filters':                          # (there the inner two filters' history block IS a small program)
+        assert any(n.startswith('voice_program[') for n in launches(timer)) == small, (which, launches(timer))
+    assert maxerr(default, f32(ref)) < 1e-6 * scale, which
 
 
 @pytest.mark.parametrize('N', [32, 64, 100])
@@ -203,7 +211,52 @@ def test_lowpass_test_patch_merge_is_two_launches():
                                 R.Fixed([[1.0]]))
     ref = R.render_stream(R.Merge(rside(p['hertz']), rside(p['hertz2']), V, V), 0, N, K, 2 * V)
     timer = KernelTimer()
-    got = render_batches(m, 2 * V, 0, N, (K,), timer)
+    got = render_batches(m, 2 * V, 0, N, (K,), timer, fuse_program='always')
     names = launches(timer)
     assert names == {'voice_program[Osc,Gain,Filter,Amp]'}, names
     assert got.shape == (N * K, 2 * V) and maxerr(got, f32(ref)) < 1e-6
+
+
+@pytest.mark.parametrize('N', [32, 50, 64, 100])
+def test_short_block_fixtures_of_the_reference(golden, N):
+    """tests/golden/small.npz -- OUTPUTS OF THE REFERENCE ITSELF: a LowPass -> HighPass cascade and a vibrato + phase wobble +
+    cutoff sweep + tremolo voice rendered sequentially in 32-, 50-, 64- and 100-frame blocks from 0 and from 4096; the engine's
+    default schedule (one interpreted launch per batch, whatever the batching) within 1e-6; three filters in series at 256"""
+    from signals_amd.chain import fx
+    from signals_amd.engine import KernelTimer
+    g = golden('small')
+    V = g['small/hertz'].shape[1]
+
+    def mod(kind, hz, depth, centre):
+        m = fx.Mix(); m.left = mkosc(kind, [[hz]]); m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r = fx.RingMod(); r.left = m; r.right = fix(centre)
+        return r
+
+    def cascade(depth=2):
+        f1 = fx.LowPass(); f1.input = mkosc('Triangle', g['small/hertz'], g['small/phase']); f1.cutoff = fix(g['small/cut1'])
+        f2 = fx.HighPass(); f2.input = f1; f2.cutoff = fix(g['small/cut2'])
+        top = f2
+        if depth == 3:
+            top = fx.LowPass(); top.input = f2; top.cutoff = fix(g['small/cut3'])
+        gn = fx.Gain(); gn.left = top; gn.right = fix(g['small/gain'])
+        return gn
+
+    def fm():
+        o = mkosc('Sawtooth', g['small/hertz'], g['small/phase'])
+        o.hertz = mod('Sine', 5.3, 0.02, g['small/hertz']); o.phase = mod('Triangle', 2.1, 0.1, g['small/phase'])
+        f = fx.LowPass(); f.input = o; f.cutoff = mod('Sine', 1.7, 0.4, g['small/cut2'])
+        gn = fx.Gain(); gn.left = f; gn.right = mod('Triangle', 3.1, 0.3, g['small/gain'])
+        return gn
+    for start in (0, 4096):
+        for name, build in (('cascade', cascade), ('fm', fm)):
+            ref = g[f'small/{name}/n{N}_p{start}']
+            timer = KernelTimer()
+            got = render_batches(build(), V, start, N, (1, 4, 2, 5), timer)
+            want = 'fused_osc_biquad[' if (name == 'fm' and N >= 100) else 'voice_program['      # (100-frame FM: the walker's own block-rate rows)
+            assert any(n.startswith(want) for n in launches(timer))
+            assert maxerr(got, f32(ref)) < 1e-6, (name, N, start)
+    if N == 32:
+        for mode in (True, 'always'):                        # three filters in series: per node by default, one launch on request
+            got = render_batches(cascade(3), V, 0, 256, (2, 1, 3), fuse_program=mode)
+            assert maxerr(got, f32(g['small/cascade3/n256_p0'])) < 1e-6, mode
+            assert maxerr(render_batches(cascade(3), V, 1000, 256, (1,), fuse_program=mode), f32(g['small/cascade3/fresh_p1000'])) < 1e-6, mode

@@ -241,6 +241,43 @@ def test_two_oscillator_and_pre_gain_voices(golden):
     assert same(R.render_stream(pre, 0, 256, 3, ref.shape[1]), ref)
 
 
+def small_block_voices(g):
+    """oracle graphs of tests/golden/small.npz (gen_golden.py: gen_small_blocks)"""
+    def lfo(kind, hz, depth, centre):
+        return R.Binary('RingMod', R.Binary('Mix', R.Osc(kind, R.Fixed([[hz]])), R.Fixed([[1.0]]), R.Fixed([[depth]])), R.Fixed(centre))
+
+    def cascade(depth=2):
+        top = R.Filter('hp', R.Filter('lp', R.Osc('Triangle', R.Fixed(g['small/hertz']), R.Fixed(g['small/phase'])), R.Fixed(g['small/cut1'])),
+                       R.Fixed(g['small/cut2']))
+        if depth == 3:
+            top = R.Filter('lp', top, R.Fixed(g['small/cut3']))
+        return R.Binary('Gain', top, R.Fixed(g['small/gain']))
+
+    def fm():
+        o = R.Osc('Sawtooth', lfo('Sine', 5.3, 0.02, g['small/hertz']), lfo('Triangle', 2.1, 0.1, g['small/phase']))
+        return R.Binary('Gain', R.Filter('lp', o, lfo('Sine', 1.7, 0.4, g['small/cut2'])), lfo('Triangle', 3.1, 0.3, g['small/gain']))
+    return cascade, fm
+
+
+@pytest.mark.parametrize('N', [32, 50, 64, 100])
+def test_blocks_no_longer_than_the_filter_context(golden, N):
+    """two filters in series and a block-rate modulated voice rendered by the REFERENCE in 32-, 50-, 64- and 100-frame blocks
+    (what a real-time sink pulls, dev.py:139-141): the context request is answered as a block of its own, the block itself by
+    the oldest cached `after` reply containing it (chain/__init__.py:431-442).  The oracle's cache restatement reproduces
+    every array bit for bit; also three filters in series at 256 frames"""
+    g = golden('small')
+    cascade, fm = small_block_voices(g)
+    for start in (0, 4096):
+        for name, build in (('cascade', cascade), ('fm', fm)):
+            ref = g[f'small/{name}/n{N}_p{start}']
+            got = R.render_stream(build(), start, N, 12, ref.shape[1])
+            assert same(got, ref), (name, N, start, float(np.abs(got - ref).max()))
+    if N == 32:
+        ref = g['small/cascade3/n256_p0']
+        assert same(R.render_stream(cascade(3), 0, 256, 6, ref.shape[1]), ref)
+        assert same(R.render(cascade(3), 1000, 256, ref.shape[1]), g['small/cascade3/fresh_p1000'])
+
+
 def test_blockloc_table(golden):
     for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
         assert R.before(int(pos), int(n), 100) == (bp, bf)
