@@ -33,7 +33,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
            'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
-           'sig_voice_program', 'sig_voice_program_set_tuning')
+           'sig_voice_program', 'sig_voice_program_set_tuning', 'sig_fused_voice_bus_rows_workspace')
 
 
 class NativeError(RuntimeError):
@@ -121,6 +121,8 @@ def lib() -> ctypes.CDLL:
                                            dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
         L.sig_fused_voice_bus_workspace.restype = ctypes.c_int64
         L.sig_fused_voice_bus_workspace.argtypes = [i32, i64, i32]
+        L.sig_fused_voice_bus_rows_workspace.restype = ctypes.c_int64
+        L.sig_fused_voice_bus_rows_workspace.argtypes = [i32, i64, i32, i32, i32]
         L.sig_fused_voice_bus.restype = ctypes.c_int
         L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                           dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
@@ -584,6 +586,54 @@ class LatencyVoiceBusCall:
         return out
 
 
+class FusedVoiceBusCall:
+    """`fused_voice_bus` with caller-held closed-form constants (sig_fused_voice_bus_prepared / _walk) and everything but the
+    position and the output buffer validated and converted ONCE: the per-batch host path of the batched engine is then one
+    ctypes call (at 256 blocks per batch the launch takes ~18 us; the generic binding's per-call validation took longer than
+    that).  The tensors are kept alive by this object."""
+
+    def __init__(self, kind: str, btype: str, rate: int, block_frames: int, nblocks: int, context: int, voices: int,
+                 hertz: torch.Tensor, phase: torch.Tensor | None, cutoff: torch.Tensor, gain: torch.Tensor | None,
+                 bus_gains: torch.Tensor | None, bus_channels: int, workspace: torch.Tensor, status: torch.Tensor | None,
+                 consts: torch.Tensor):
+        _gpu(hertz, phase, cutoff, gain, bus_gains, workspace, status, consts)
+        rows = block_frames * nblocks
+        ptrs = []
+        for row, name in ((hertz, 'hertz'), (phase, 'phase'), (cutoff, 'cutoff'), (gain, 'gain')):
+            if row is not None and row.shape[1] not in (1, voices):
+                raise NativeError(f'{name} has {row.shape[1]} channels for {voices} voices')
+            ptrs.extend(_ctrl_row(row, name))
+        gp, gld = None, 0
+        if bus_gains is not None:
+            if bus_gains.dtype != torch.float64 or bus_gains.shape != (bus_channels, voices) or bus_gains.stride(1) != 1:
+                raise NativeError(f'bus gains must be float64 ({bus_channels},{voices}), got {tuple(bus_gains.shape)} {bus_gains.dtype}')
+            gp, gld = bus_gains.data_ptr(), bus_gains.stride(0)
+        elif bus_channels != 1:
+            raise NativeError('a bus without gains is mono')
+        if workspace.dtype != torch.float64 or workspace.numel() * 8 < lib().sig_fused_voice_bus_workspace(voices, rows, bus_channels):
+            raise NativeError('fused bus workspace too small')
+        if consts.dtype != torch.float64 or consts.numel() * 8 < lib().sig_fused_voice_consts_size(voices):
+            raise NativeError('consts must be float64 of sig_fused_voice_consts_size(voices) bytes')
+        self._keep = (hertz, phase, cutoff, gain, bus_gains, workspace, status, consts)
+        self._head = (OSC_KINDS[kind], FILT_TYPES[btype], rate)
+        self._mid = (block_frames, nblocks, context, voices, *ptrs, gp, gld, bus_channels, workspace.data_ptr())
+        self._status = status.data_ptr() if status is not None else None
+        self._consts = consts.data_ptr()
+        self._prepared, self._walk = lib().sig_fused_voice_bus_prepared, lib().sig_fused_voice_bus_walk
+        self.shape = (rows, bus_channels)
+
+    def __call__(self, position: int, out: torch.Tensor, consts_ready: bool, walk: bool = False) -> torch.Tensor:
+        """`out`: a contiguous float32 (nblocks * block_frames, bus_channels) tensor on the launch device"""
+        if walk:
+            err = self._walk(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, _stream(out))
+        else:
+            err = self._prepared(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, _stream(out),
+                                 self._consts, 1 if consts_ready else 0)
+        if err:
+            raise NativeError(f'sig_fused_voice_bus failed: hipError_t {err}')
+        return out
+
+
 def fused_geometry(voices: int, block_frames: int, nblocks: int, context: int) -> tuple[int, int]:
     """(voices per lane, blocks per lane) the fused kernels use for this problem size"""
     vpt, span = ctypes.c_int32(), ctypes.c_int32()
@@ -697,7 +747,7 @@ def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: in
         bp, bld = bus_gains.data_ptr(), bus_gains.stride(0)
     elif C != 1:
         raise NativeError('a bus without gains is mono')
-    need = lib().sig_fused_voice_bus_workspace(voices, rows, C)
+    need = lib().sig_fused_voice_bus_rows_workspace(voices, rows, C, nblocks, crows)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
     if pargs is not None:

@@ -457,6 +457,10 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // block (c = min(ctx, position)), and the decay bound.
 enum { SC_NA1, SC_NA2, SC_SCALE, SC_K2C, SC_ST, SC_CT, SC_HRE, SC_HIM, SC_ND, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
 
+// ... and, where the cutoff (and the gain) is read per block (an LFO sweep: forward_at_block_rate, chain/__init__.py:305-306;
+// fx.py:127-129), what depends on the filter per (block, voice): [kRowConsts][K][voices], made by steady_prep_rows_kernel
+enum { RC_NA1, RC_NA2, RC_SCALE, RC_HRE, RC_HIM, RC_ND, RC_T, kRowConsts = RC_T + 4 };
+
 // does the steady kernel take the wave of voices [v0, v0 + vpt) x 64 lanes for the span starting at frame p0?
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb) {
     const double q_first = (double)p0 / a.rate, q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
@@ -483,6 +487,26 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
     put(SC_HRE, c.hre); put(SC_HIM, c.him); put(SC_ND, c.nd);
     put(SC_T + 0, c.T.a); put(SC_T + 1, c.T.b); put(SC_T + 2, c.T.c); put(SC_T + 3, c.T.d);
     put(SC_T0 + 0, c.T0.a); put(SC_T0 + 1, c.T0.b); put(SC_T0 + 2, c.T0.c); put(SC_T0 + 3, c.T0.d);
+}
+
+// one thread per (block, voice): the filter of that block (cutoff row b, gain row b or the one gain row), its response at the
+// voice's frequency, T_c for the block's context (only the launch's first block can have a short one) and the decay bound
+__global__ __launch_bounds__(256) void steady_prep_rows_kernel(FusedArgs a, double* __restrict__ rc)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.K * a.voices) return;
+    const int64_t b = idx / a.voices;
+    const int v = (int)(idx - b * a.voices);
+    const double cutoff = a.cutoff[(a.cutoff_rows > 1 ? b * (int64_t)(a.cs ? a.voices : 1) : 0) + (int64_t)v * a.cs];
+    const double gain = a.gain ? a.gain[(a.gain_rows > 1 ? b * (int64_t)(a.gs ? a.voices : 1) : 0) + (int64_t)v * a.gs] : 1.0;
+    const int64_t p_b = a.position + b * a.N;
+    const int c_b = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
+    const SteadyVoice c = steady_constants_of<true>(a, v, cutoff, gain, c_b);
+    if (!c.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+    const int64_t plane = (int64_t)a.K * a.voices;
+    auto put = [&](int k, double x) { rc[(int64_t)k * plane + idx] = x; };
+    put(RC_NA1, c.na1); put(RC_NA2, c.na2); put(RC_SCALE, c.scale); put(RC_HRE, c.hre); put(RC_HIM, c.him); put(RC_ND, c.nd);
+    put(RC_T + 0, c.T0.a); put(RC_T + 1, c.T0.b); put(RC_T + 2, c.T0.c); put(RC_T + 3, c.T0.d);
 }
 
 // The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^26 cycles), done inside the
@@ -520,12 +544,15 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
                 const int v = live ? v0 + i : vc;
                 const double t = q * a.hertz[(int64_t)v * a.hs] + (a.phase ? a.phase[(int64_t)v * a.ps] : 0.0);
                 const double x = (double)sig_osc::osc_sine_f32(t);
-                const double na1 = sc[(int64_t)SC_NA1 * a.voices + v], na2 = sc[(int64_t)SC_NA2 * a.voices + v];
+                const double* rc = a.steady_rows;                                  // per-block cutoff rows: the block's own filter
+                const int64_t at = (b_first + bi) * (int64_t)a.voices + v, plane = (int64_t)a.K * a.voices;
+                const double na1 = rc ? rc[RC_NA1 * plane + at] : sc[(int64_t)SC_NA1 * a.voices + v];
+                const double na2 = rc ? rc[RC_NA2 * plane + at] : sc[(int64_t)SC_NA2 * a.voices + v];
                 const double y = x + z0[i];
                 z0[i] = fma(na1, y, fma(s2, x, z1[i]));
                 z1[i] = fma(na2, y, x);
-                double scale = live ? sc[(int64_t)SC_SCALE * a.voices + v] : 0.0;
-                if (a.gain_rows > 1) scale *= a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];   // per-block gain rows (the constants then hold b0 only)
+                double scale = live ? (rc ? rc[RC_SCALE * plane + at] : sc[(int64_t)SC_SCALE * a.voices + v]) : 0.0;
+                if (!rc && a.gain_rows > 1) scale *= a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];   // per-block gain rows (the constants then hold b0 only)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) acc[ch] = fma(bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale, y, acc[ch]);
             }
@@ -567,7 +594,10 @@ template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ?
 
 // GROWS: the gain is read per block (a tremolo: sig_fused_voice_bus_rows with rows for the gain only); the constants then hold
 // b0 alone and the bus weights are rebuilt at every block's first row
-template <int VPT, int C, bool GROWS>
+// CROWS: the cutoff (and possibly the gain) is read per block: the filter, its response H, T_c and the decay bound come from
+// the per-(block, voice) constants, the steady-state recurrence is re-seeded at every block's first row with that block's H
+// (the oscillator itself runs on: the phase of the row is recomputed from the reference's own t, two sines per voice and block)
+template <int VPT, int C, bool GROWS, bool CROWS = false>
 __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
 {
     constexpr int R = kPairs / C;          // rows per flush
@@ -618,9 +648,20 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
         yb[i] = wi;
         ya[i] = fma(wi, cst(SC_CT), -(wr * cst(SC_ST)));
         const double nd = cst(SC_ND);
-        const int mine = (live && nd < (double)kNeverDrops) ? (int)nd : (live ? kNeverDrops : 0);   // NaN: never
-        nd_total[i] = wave_max_int(mine);
+        nd_total[i] = (live && nd < (double)kNeverDrops) ? (int)nd : (live ? kNeverDrops : 0);   // NaN: never
     }
+    // ... per voice SLOT: the wave maximum, the VPT butterflies side by side (one after the other their cross-lane round trips
+    // were a tenth of a one-block span)
+#pragma unroll
+    for (int d = 1; d < SIG_WAVE; d <<= 1) {
+        int other[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) other[i] = __shfl_xor(nd_total[i], d, SIG_WAVE);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) nd_total[i] = (other[i] > nd_total[i]) ? other[i] : nd_total[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) nd_total[i] = __builtin_amdgcn_readfirstlane(nd_total[i]);
 
     double* dstp = bus.partials + (int64_t)vt * bus.rows * C;                  // [tile][row][c]
     sig_bus::PipelinedTile<C> stage(tile, lane, dstp, b_first * a.N);
@@ -734,7 +775,7 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
     using Variants = SteadyVariants<VPT>;
 
     for (int bi = 0; bi < nb; ++bi) {
-        if constexpr (GROWS) {
+        if constexpr (GROWS && !CROWS) {
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 const bool live = v0 + i < a.voices;
@@ -748,16 +789,58 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
         const bool first = (b_first + bi == 0);
         const int tk = first ? SC_T0 : SC_T;
         const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
+        const double* tbase = sc + (int64_t)tk * a.voices;                     // T_c of voice v at tbase[k * tstride + v]
+        int64_t tstride = a.voices;
+        if constexpr (CROWS) {
+            // this block's filter: coefficients, bus weights, the steady-state seeds from its H, the decay bound per slot
+            const double* rc = a.steady_rows;
+            const int64_t plane = (int64_t)a.K * a.voices, at0 = (b_first + bi) * (int64_t)a.voices;
+            const double q_b = (double)(p0 + (int64_t)bi * a.N) / a.rate;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const bool live = v0 + i < a.voices;
+                const int v = live ? v0 + i : vc;
+                auto row = [&](int k) { return rc[(int64_t)k * plane + at0 + v]; };
+                const double na1_i = row(RC_NA1);
+                if (i < LC) { na1[i < LC ? i : 0] = na1_i; na2[i < LC ? i : 0] = row(RC_NA2); }
+                if (live && na1_i != na1_i && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
+                const double scale = row(RC_SCALE);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0;
+                const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+                const double t_first = q_b * hz + ph;                          // osc.py:32
+                const double f0 = t_first - rint(t_first);
+                const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
+                const double hre = row(RC_HRE), him = row(RC_HIM);
+                const double wr = fma(hre, ur, -(him * ui)), wi = fma(hre, ui, him * ur);
+                yb[i] = wi;
+                ya[i] = fma(wi, sc[(int64_t)SC_CT * a.voices + v], -(wr * sc[(int64_t)SC_ST * a.voices + v]));
+                const double nd = row(RC_ND);
+                nd_total[i] = (live && nd < (double)kNeverDrops) ? (int)nd : (live ? kNeverDrops : 0);
+            }
+#pragma unroll
+            for (int d = 1; d < SIG_WAVE; d <<= 1) {
+                int other[VPT];
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) other[i] = __shfl_xor(nd_total[i], d, SIG_WAVE);
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) nd_total[i] = (other[i] > nd_total[i]) ? other[i] : nd_total[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) nd_total[i] = __builtin_amdgcn_readfirstlane(nd_total[i]);
+            tbase = rc + (int64_t)RC_T * plane + at0;
+            tstride = plane;
+        }
         int drop_at[LC];                                                       // row of the block from which slot i is dropped
 #pragma unroll
         for (int i = 0; i < LC; ++i) {
             drop_at[i] = (nd_total[i] > c) ? nd_total[i] - c : 0;              // wave-uniform
             if (drop_at[i] > 0) {
                 const int v = (v0 + i < a.voices) ? v0 + i : vc;
-                const double* t = sc + (int64_t)tk * a.voices + v;
+                const double* t = tbase + v;
                 const double dss = fma(k2c[i], yb[i], -ya[i]) - yb[i];          // yss_{p+1} - yss_p
-                z0h[i] = fma(t[0], yb[i], t[a.voices] * dss);
-                z1h[i] = fma(t[2 * (int64_t)a.voices], yb[i], t[3 * (int64_t)a.voices] * dss);
+                z0h[i] = fma(t[0], yb[i], t[tstride] * dss);
+                z1h[i] = fma(t[2 * tstride], yb[i], t[3 * tstride] * dss);
             } else {
                 z0h[i] = 0.0; z1h[i] = 0.0;
             }
@@ -802,20 +885,24 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
     if (stage.staged) stage.now();
 }
 
-template <int VPT, int C, bool GROWS = false>
+template <int VPT, int C, bool GROWS = false, bool CROWS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
 void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     __shared__ double lds[4][kPairs * kTileStride];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
-    steady_bus_wave<VPT, C, GROWS>(a, bus, lds[wave], lane, wave);             // everything derived from it lives in SGPRs and branches are scalar
+    steady_bus_wave<VPT, C, GROWS, CROWS>(a, bus, lds[wave], lane, wave);      // everything derived from it lives in SGPRs and branches are scalar
     if (bus.out) sig_bus::sum_tiles_in_workgroup<C>(bus.partials, a.voice_tiles, bus.rows, a.span, a.K, a.N, bus.out, bus.out_ld, lane, wave);
 }
 
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
+// ( + [per-(block, voice) constants] for sig_fused_voice_bus_rows with per-block cutoff rows: sig_fused_voice_bus_rows_workspace)
 int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
     return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
+}
+int64_t steady_rows_offset(int voices, int64_t rows, int bus_channels) {
+    return steady_consts_offset(voices, rows, bus_channels) + (int64_t)kSteadyConsts * voices;
 }
 
 // Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
@@ -874,7 +961,7 @@ int launch_walk(FusedArgs a, BusArgs bus, int vpt, hipStream_t stream)
 
 struct BusPlan { int vpt, span, steady; };
 BusPlan plan_voice_bus(const FusedArgs& a, int kind);
-template <bool GAIN, int C, bool GROWS>
+template <bool GAIN, int C, bool GROWS, bool CROWS = false>
 int launch_steady(FusedArgs& a, BusArgs& bus, int vpt, float* out, int64_t out_ld, hipStream_t stream);
 
 // the per-block-parameter entry points (sig_fused_osc_biquad_rows, sig_fused_voice_bus_rows, *_fm, *_pair): the walker --
@@ -884,12 +971,17 @@ template <int KIND, int C>
 int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_t stream)
 {
     if constexpr (KIND == SIG_OSC_SINE && C > 0) {
-        if (a.gain && a.gain_rows > 1 && a.cutoff_rows == 1 && !a.hertz_hist && !a.phase_hist && a.pair_op == 0) {
-            const BusPlan plan = plan_voice_bus(a, KIND);
+        const bool gain_only = a.gain && a.gain_rows > 1 && a.cutoff_rows == 1;
+        if ((gain_only || a.cutoff_rows > 1) && !a.hertz_hist && !a.phase_hist && a.pair_op == 0) {
+            BusPlan plan = plan_voice_bus(a, KIND);
             if (plan.steady) {
+                if (plan.vpt > 8) plan.vpt = 8;
                 a.span = plan.span;
                 a.steady = 1;
-                const int err = launch_steady<false, C, true>(a, bus, plan.vpt, out, out_ld, stream);
+                // a swept cutoff (with or without a tremolo): per-(block, voice) filter constants; a tremolo alone: the bus
+                // weights rebuilt per block
+                const int err = gain_only ? launch_steady<false, C, true>(a, bus, plan.vpt, out, out_ld, stream)
+                                          : launch_steady<false, C, true, true>(a, bus, plan.vpt, out, out_ld, stream);
                 if (err || bus.out) return err;
                 const int tiles_s = (a.voices + SIG_WAVE * plan.vpt - 1) / (SIG_WAVE * plan.vpt);
                 return sig_bus::launch_partials<C>(bus.partials, tiles_s, bus.rows, out, out_ld, stream);
@@ -956,23 +1048,29 @@ BusPlan plan_voice_bus(const FusedArgs& a, int kind) {
 
 // the closed form: per-voice constants, then one launch (closed form per wave, or its built-in plain fallback
 // steady_fallback_span); sets bus.out when the kernel adds the voice tiles itself
-template <bool GAIN, int C, bool GROWS>
+template <bool GAIN, int C, bool GROWS, bool CROWS>
 int launch_steady(FusedArgs& a, BusArgs& bus, int vpt, float* out, int64_t out_ld, hipStream_t stream)
 {
     double* consts = a.consts_ext ? a.consts_ext : bus.partials + steady_consts_offset(a.voices, bus.rows, C);
     a.steady_consts = consts;
     if (!(a.consts_ext && a.consts_ready))
         steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
+    if constexpr (CROWS) {
+        double* rc = bus.partials + steady_rows_offset(a.voices, bus.rows, C);
+        const int64_t n = (int64_t)a.K * a.voices;
+        steady_prep_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, rc);
+        a.steady_rows = rc;
+    }
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     if (sig_bus::tiles_sum_in_workgroup(a.voice_tiles) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
     switch (vpt) {
-        case 1: fused_steady_bus_kernel<1, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 2: fused_steady_bus_kernel<2, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 8: fused_steady_bus_kernel<8, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        case 16: fused_steady_bus_kernel<16, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
-        default: fused_steady_bus_kernel<4, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 1: fused_steady_bus_kernel<1, C, GROWS, CROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 2: fused_steady_bus_kernel<2, C, GROWS, CROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 8: fused_steady_bus_kernel<8, C, GROWS, CROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
+        case 16: if constexpr (!CROWS) { fused_steady_bus_kernel<16, C, GROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break; }
+        default: fused_steady_bus_kernel<4, C, GROWS, CROWS><<<(unsigned)nwg, 256, 0, stream>>>(a, bus); break;
     }
     return sig_launch_status();
 }
@@ -1448,6 +1546,12 @@ extern "C" int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_
     t.tile_sum_kernel = (closed_form == 2) ? 1 : 0;
     t.mix_f32 = (closed_form == 3) ? 1 : 0;                                    // 3: closed form on, the MixMatrix sink on v_mfma_f32_32x32x2_f32
     return 0;
+}
+
+extern "C" int64_t sig_fused_voice_bus_rows_workspace(int32_t voices, int64_t rows, int32_t bus_channels, int32_t nblocks, int32_t cutoff_rows)
+{
+    const int64_t base = steady_rows_offset(voices, rows, bus_channels);
+    return (base + (cutoff_rows > 1 ? (int64_t)kRowConsts * nblocks * voices : 0)) * (int64_t)sizeof(double);
 }
 
 extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)

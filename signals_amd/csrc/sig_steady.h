@@ -20,6 +20,7 @@ struct FusedArgs {
     int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
     int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
+    const double* steady_rows = nullptr;     // ... per (block, voice) where the cutoff (and the gain) is read per block: [kRowConsts][K][voices]
     double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
     int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
@@ -50,7 +51,8 @@ __device__ __forceinline__ M2 m2_mul(const M2& x, const M2& y) {
     return {fma(x.a, y.a, x.b * y.c), fma(x.a, y.b, x.b * y.d), fma(x.c, y.a, x.d * y.c), fma(x.c, y.b, x.d * y.d)};
 }
 
-constexpr double kHomogeneousTol = 1e-11;     // of one voice's full scale (unit-amplitude oscillator, before gain and pan)
+constexpr double kHomogeneousTol = 1e-9;      // of one voice's full scale (unit-amplitude oscillator, before gain and pan): a bus of V voices is off by
+                                              // at most V x 1e-9 x |weight| where every dropped part adds up coherently -- 5e-8 of ITS full scale (~ sqrt(V) weights)
 
 // per-row phase step and whether the closed form applies to a voice for rows [first, last]: |t| < 2^26 cycles over
 // the span (as for the walker's Sine recurrence), at most a quarter turn per row, and sin(theta) not tiny (the map
@@ -65,13 +67,14 @@ __device__ __forceinline__ bool steady_voice_ok(double hz, double ph, double rat
 
 struct SteadyVoice { bool ok; double na1, na2, scale, k2c, st, ct, hre, him, nd; M2 T, T0; };
 
+// `cutoff`, `gain`: the voice's values (of one block, when they are read per block); `c_first`: the context of the launch's first block
 template <bool GAIN>
-__device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int v)
+__device__ __forceinline__ SteadyVoice steady_constants_of(const FusedArgs& a, int v, double cutoff, double gain, int c_first)
 {
     using sig_biquad::Cx; using sig_biquad::cx_mul; using sig_biquad::cx_div;
     SteadyVoice r;
     Biquad q;
-    r.ok = design_butter2(a.type, a.cutoff[(int64_t)v * a.cs], a.rate, q);
+    r.ok = design_butter2(a.type, cutoff, a.rate, q);
     const double s2 = (a.type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;                // b1 / b0
     const double a1 = q.a1, a2 = q.a2;
     const double d = a.hertz[(int64_t)v * a.hs] / a.rate;
@@ -98,8 +101,7 @@ __device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int 
         return M2{-t.a, -t.b, -t.c, -t.d};
     };
     r.T = make_T(a.ctx);
-    const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
-    r.T0 = (c0 == a.ctx) ? r.T : make_T(c0);
+    r.T0 = (c_first == a.ctx) ? r.T : make_T(c_first);
     // Rows after a cold start until the homogeneous part is below kHomogeneousTol of the voice's full scale, for good:
     // in the coordinates S x in which A is a rotation times the pole radius rho = sqrt(a2) the state shrinks by exactly
     // rho per row, so |yh_n| <= cond(S) rho^n |x_0| with x_0 = minus the steady-state DF2T state, |x_0| <= sqrt(|P|^2 + |Q|^2)
@@ -117,9 +119,16 @@ __device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int 
         }
     }
     r.na1 = -a1; r.na2 = -a2;
-    r.scale = GAIN ? q.b0 * a.gain[(int64_t)v * a.gs] : q.b0;
+    r.scale = GAIN ? q.b0 * gain : q.b0;
     r.k2c = 2.0 * ct; r.st = st; r.ct = ct; r.hre = H.re; r.him = H.im;
     return r;
+}
+
+template <bool GAIN>
+__device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int v)
+{
+    const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
+    return steady_constants_of<GAIN>(a, v, a.cutoff[(int64_t)v * a.cs], GAIN ? a.gain[(int64_t)v * a.gs] : 1.0, c0);
 }
 
 __device__ __forceinline__ int wave_max_int(int x) {

@@ -1355,20 +1355,45 @@ class _VoiceChain:
         if self.general:
             if bus_c not in (1, 2):
                 return None
-            if (self.kind == 'Sine' and self.pair is None and not self.fm and controls[2].shape[0] == 1
-                    and controls[3] is not None and controls[3].shape[0] > 1 and controls[3].shape[1] == v):
-                # a tremolo is the only modulation: sig_fused_voice_bus_rows keeps the closed form for it, and the closed form
-                # wants its voices ordered by cutoff (ordered_by_cutoff); the order is kept while the constant rows are
+            swept = controls[2].shape[0] > 1                                    # the cutoff is read per block
+            if swept:
+                need = _native.lib().sig_fused_voice_bus_rows_workspace(v, rows, bus_c, K, controls[2].shape[0]) // 8
+                if o._workspace.numel() < need:
+                    o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=dev)
+            if (self.kind == 'Sine' and self.pair is None and not self.fm and controls[2].shape[1] == v
+                    and (swept or (controls[3] is not None and controls[3].shape[0] > 1 and controls[3].shape[1] == v))):
+                # a swept cutoff and / or a tremolo: sig_fused_voice_bus_rows keeps the closed form (per-block filter constants,
+                # bus weights rebuilt per block), and the closed form wants its voices ordered by cutoff (ordered_by_cutoff: it
+                # drops the decayed homogeneous part per voice slot); the order is kept while the constant rows are.  Under a
+                # sweep the order of the batch's first row stands for all of them (an LFO scales every voice's cutoff alike;
+                # any order is correct) -- sorted on the device, no host round trip
                 held = o._tremolo_order
-                key = (id(controls[0]), id(controls[1]), id(controls[2]), id(pan), K)
+                key = (id(controls[0]), id(controls[1]), id(controls[2]) if not swept else None, id(pan), K, swept)
                 if held is None or held[0] != key:
                     plan = _native.fused_voice_bus_plan('Sine', b.pos, v, N, K, CONTEXT)
-                    index = self.cutoff_order(controls, plan['voices_per_lane']) if plan['closed_form'] else None
+                    vpl = min(plan['voices_per_lane'], 8)
+                    if not plan['closed_form']:
+                        index = None
+                    elif not swept:
+                        index = self.cutoff_order(controls, vpl)
+                    else:
+                        tile, tiles = 64 * vpl, v // (64 * vpl)
+                        order = torch.argsort(controls[2][0], stable=True)
+                        index = order.clone()                                    # (a ragged last tile stays lane-major)
+                        if tiles:
+                            q = torch.arange(tiles * tile, device=dev)
+                            group, lane = q // 64, q % 64
+                            index[((group % tiles) * 64 + lane) * vpl + group // tiles] = order[q]
                     pick = lambda t: t if t is None or index is None or t.shape[1] != v else t.index_select(1, index).contiguous()
                     held = o._tremolo_order = (key, (controls[0], controls[1], controls[2], pan), index,
-                                               [pick(controls[0]), pick(controls[1]), pick(controls[2])], pick(pan))
+                                               [pick(controls[0]), pick(controls[1]), None if swept else pick(controls[2])], pick(pan))
                 if held[2] is not None:
-                    controls = held[3] + [controls[3].index_select(1, held[2])]
+                    pick = lambda t: t if t is None or t.shape[1] != v else t.index_select(1, held[2])
+                    cut = pick(controls[2]) if swept else held[3][2]
+                    gain_rows = controls[3]
+                    if gain_rows is not None and gain_rows.shape[1] == v:
+                        gain_rows = pick(gain_rows)
+                    controls = [held[3][0], held[3][1], cut, gain_rows]
                     pan = held[4]
             out = torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev)
             return o._launch(f'fused_voice_bus[{self.tag}]',
@@ -1416,6 +1441,15 @@ class _VoiceChain:
             # last frame puts the fastest voice past the limit, the span walker takes the whole launch instead.
             per_frame, ph_max = held[3]
             walk = self.kind == 'Sine' and ph_max + (position + rows) * per_frame >= _native.SINE_FAST_MAX_CYCLES
+            if o.timer is None:
+                # the per-batch host path: one pre-bound ctypes call (the binding's per-call validation cost more than the launch at
+                # 256 blocks per batch); bound per set of constants, i.e. while the parameter uploads are the same tensors
+                call = held[5] if len(held) > 5 else None
+                if call is None or call.shape != (rows, bus_c) or call._keep[5] is not o._workspace:
+                    call = _native.FusedVoiceBusCall(self.kind, self.btype, rate, N, K, CONTEXT, v, ctl[0], ctl[1], ctl[2], ctl[3], pan_now,
+                                                     bus_c, o._workspace, status, held[2])
+                    o._steady_consts = held = (*held[:5], call)
+                return call(position, out, ready, walk)
             return o._launch(bus_name, lambda: _native.fused_voice_bus(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
                                                                        ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
                                                                        workspace=o._workspace, status=status,

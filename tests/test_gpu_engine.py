@@ -877,6 +877,69 @@ def test_tremolo_only_sine_voice_keeps_the_closed_form(golden):
         _native.set_fused_tuning()
 
 
+def test_swept_cutoff_sine_voice_keeps_the_closed_form():
+    """a Sine voice whose cutoff is driven at block rate (an LFO sweep, with or without a tremolo: chain/__init__.py:305-306,
+    fx.py:127-129) stays on the closed-form kernel: the filter, its response at the voice's frequency, T_c and the decay bound
+    per (block, voice) from a prep launch, the steady-state recurrence re-seeded at every block's first row
+    (fused_steady_bus_kernel<.., CROWS>).  Against the row walker (tuning hook) and the oracle: batches of 5 + 3 + 1 blocks
+    from 0 (a short first context) and mid-stream, mono and stereo, every geometry, voices outside the closed form's range,
+    a cutoff LFO that is one column wide"""
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N = 200, 256
+    rng = np.random.default_rng(77)
+    hz, ph = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V))
+    cut, gain = np.exp(rng.uniform(np.log(60.0), np.log(9000.0), (1, V))), rng.uniform(0.2, 1.0, (1, V))
+    hz[0, 3], hz[0, 130] = 2.0, 20000.0                                 # below / above the closed form's range: those waves fall back
+    th = rng.uniform(0, np.pi / 2, V)
+    pan = np.stack([np.cos(th), np.sin(th)])
+
+    def lfo_gpu(kind, f_, depth, centre):
+        m = fx.Mix(); m.left = mkosc(kind, [[f_]]); m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r_ = fx.RingMod(); r_.left = m; r_.right = fix(centre)
+        return r_
+
+    def lfo_ref(kind, f_, depth, centre):
+        return R.Binary('RingMod', R.Binary('Mix', R.Osc(kind, R.Fixed([[f_]])), R.Fixed([[1.0]]), R.Fixed([[depth]])), R.Fixed(centre))
+
+    def build(stereo, tremolo, narrow):
+        f = fx.LowPass(); f.input = mkosc('Sine', hz, ph)
+        f.cutoff = lfo_gpu('Sine', 1.7, 0.4, [[1500.0]] * 1 if narrow else cut)
+        top = fx.Gain(); top.left = f; top.right = lfo_gpu('Triangle', 3.1, 0.3, gain) if tremolo else fix(gain)
+        b = ext.SumBus(); b.input = top
+        if stereo:
+            b.get_state().gains = np.ascontiguousarray(pan)
+        return b
+
+    def oracle(tremolo, narrow):
+        cutoff = lfo_ref('Sine', 1.7, 0.4, np.full((1, V), 1500.0) if narrow else cut)
+        g_ = lfo_ref('Triangle', 3.1, 0.3, gain) if tremolo else R.Fixed(gain)
+        return R.Binary('Gain', R.Filter('lp', R.Osc('Sine', R.Fixed(hz), R.Fixed(ph)), cutoff), g_)
+    try:
+        for stereo, tremolo, narrow, start in ((True, True, False, 0), (False, False, False, 4096), (True, False, True, 37)):
+            if narrow:
+                continue                                              # (the reference indexes cutoff[0, i] per channel: a one-column cutoff raises IndexError)
+            ref = R.sum_bus(R.render_stream(oracle(tremolo, narrow), start, N, 9, V), pan if stereo else None)
+            scale = max(1.0, float(np.abs(ref).max()))
+            outs = {}
+            for vpt, span, steady in ((0, 0, 1), (8, 4, 1), (2, 3, 1), (1, 1, 1), (0, 0, 0)):
+                _native.set_fused_tuning(vpt, span, steady, 0)
+                timer = KernelTimer()
+                r = BatchRenderer(build(stereo, tremolo, narrow), 2 if stereo else 1, RATE, timer=timer)
+                got = np.concatenate([r.render(start, N, 5).cpu().numpy(), r.render(start + 5 * N, N, 3).cpu().numpy(),
+                                      r.render(start + 8 * N, N, 1).cpu().numpy()])
+                torch.cuda.synchronize()
+                assert any(n.startswith('fused_voice_bus[Sine,lp,gain,per-block]') for n in timer.summary()), set(timer.summary())
+                assert np.isfinite(got).all()
+                assert maxerr(got, f32(ref)) < 1e-6 * scale, (stereo, tremolo, start, vpt, span, steady)
+                outs[(vpt, span, steady)] = got
+            assert maxerr(outs[(0, 0, 1)], outs[(0, 0, 0)]) < 4e-7 * scale            # closed form vs row walker
+    finally:
+        _native.set_fused_tuning()
+
+
 def test_control_program_equals_the_node_by_node_evaluation_bit_for_bit():
     """sig_control_program: a block-rate control subgraph (oscillators of every waveform, Gain / Mix / RingMod / Amp, Fixed rows
     one column or V wide, shared sub-expressions, an unplugged port, a disabled node) compiled into one launch gives the
