@@ -67,7 +67,7 @@ def steady_applies(p, lo, hi, first_frame, last_frame, N, ctx=100):
                 and (N >= ctx or first_frame >= ctx))
 
 
-def closed_form_live_fraction(p, lo, hi, N, vpt, ctx=100, bus_channels=2, tol=1e-11):
+def closed_form_live_fraction(p, lo, hi, N, vpt, ctx=100, bus_channels=2, tol=1e-9):
     """Host mirror of what fused_steady_bus_kernel does with the bench's voices: the fraction of (voice slot, row) pairs
     whose homogeneous part is still carried.  Mirrors steady_prep_kernel's decay bound (rows from the cold start until
     the homogeneous part is below `tol` of the voice's full scale), the engine's voice order (engine.py:
@@ -372,13 +372,15 @@ def run_modulated(K: int = 1024, steps: int = 30, prewarm_s: float = 0.5) -> dic
     warnings.filterwarnings('ignore', category=DeprecationWarning)
     V, N = 1024, 256
     p = cfg.c2_params(V)
-    out = {'workload': f'C2 voices ({V}) with block-rate vibrato + cutoff sweep + tremolo, {N}-frame blocks, {K} blocks per batch',
+    out = {'workload': f'C2 voices ({V}) with block-rate modulation (vibrato / cutoff sweep / tremolo), {N}-frame blocks, {K} blocks per batch',
            'unit': 'Msamples/s', 'voices': {}}
-    for kind in ('Sawtooth', 'Sine'):
+    legs = {'Sawtooth': ('Sawtooth', True, True, True), 'Sine': ('Sine', True, True, True),
+            'Sine_sweep_tremolo': ('Sine', False, True, True), 'Sine_sweep': ('Sine', False, True, False)}
+    for label, (kind, vibrato, sweep, tremolo) in legs.items():
         timer = KernelTimer(sample_every=4)
-        r = BatchRenderer(cfg.c2_modulated_graph(p, kind), 2, RATE, timer=timer)
+        r = BatchRenderer(cfg.c2_modulated_graph(p, kind, vibrato, sweep, tremolo), 2, RATE, timer=timer)
         first = r.render(0, N, K)
-        node, pan = cfg.c2_modulated_oracle(p, kind)
+        node, pan = cfg.c2_modulated_oracle(p, kind, vibrato, sweep, tremolo)
         ref = R.sum_bus(R.render_stream(node, 0, N, 2, V), pan).astype(np.float32).astype(np.float64)
         err = float(np.max(np.abs(first[:2 * N].double().cpu().numpy() - ref)))
         pos = N * K
@@ -393,9 +395,29 @@ def run_modulated(K: int = 1024, steps: int = 30, prewarm_s: float = 0.5) -> dic
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         summ = timer.summary()
-        out['voices'][kind] = {'value': V * N * K * steps / dt / 1e6, 'ms_per_step': dt / steps * 1e3,
-                               'max_abs_error_blocks_0_1': err, 'full_scale': float(np.max(np.abs(ref))),
-                               'launches_per_step': {k: round(v['ms'] / v['calls'], 4) for k, v in summ.items()}}
+        out['voices'][label] = {'modulation': '+'.join(n for n, on in (('vibrato', vibrato), ('cutoff sweep', sweep), ('tremolo', tremolo)) if on),
+                                'value': V * N * K * steps / dt / 1e6, 'ms_per_step': dt / steps * 1e3,
+                                'max_abs_error_blocks_0_1': err, 'full_scale': float(np.max(np.abs(ref))),
+                                'launches_per_step': {k: round(v['ms'] / v['calls'], 4) for k, v in summ.items()}}
+    return out
+
+
+def run_programs(K: int = 1024, steps: int = 10) -> dict:
+    """Graph shapes none of the fused kernels covers (a Mix or a RingMod behind filters, a modulated cascade ...): ONE interpreted
+    launch per batch (sig_voice_program) against the same graph one kernel per node -- tools/time_voice_program.py; 1024 voices under a
+    stereo bus, 256-frame blocks.  Not a BASELINE configuration: what the reference's node API allows beyond them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('time_voice_program', ROOT / 'tools' / 'time_voice_program.py')
+    tvp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tvp)
+    V, N = 1024, 256
+    out = {'workload': f'{V} voices under a stereo bus, {N}-frame blocks, {K} blocks per batch', 'unit': 'Msamples/s', 'shapes': {}}
+    for name, build in tvp.shapes(V).items():
+        if name in ('amp_after_filter', 'three_filters', 'osc_gain_only'):
+            continue                                     # (the interpreter's full register file loses to one kernel per node: the engine does not pick it)
+        fast, launches = tvp.rate(build, V, N, K, True, steps=steps)
+        slow, _ = tvp.rate(build, V, N, K, False, steps=4)
+        out['shapes'][name] = {'value': fast * 1e6, 'one_kernel_per_node': slow * 1e6, 'launches_us': launches}
     return out
 
 
@@ -451,8 +473,10 @@ def main():
     def measure(fuse: bool, steps: int, warmup: int, sustained_s: float = 0.0) -> dict:
         """W untimed + exactly `steps` timed batches of this rank's 1024-voice graph (+ bus reduce); then, optionally,
         the same steps for `sustained_s` more seconds"""
-        # fused schedule: one ~200-us launch per step -- every 8th is bracketed by HIP events; node-materialised: all of them
-        timer = None if args.no_kernel_timing else KernelTimer(sample_every=8 if fuse else 1)
+        # fused schedule: one ~200-us launch per step -- ONE HIP event in front of the first timed launch and one behind the last
+        # (nothing between the launches: the stream runs as it does untimed, so avg_launch_ms is the per-step GPU time, gaps
+        # included, and cannot exceed ms_per_step); node-materialised: every launch bracketed
+        timer = None if args.no_kernel_timing else (KernelTimer(region=True) if fuse else KernelTimer(sample_every=1))
         renderer = parallel.ShardedRenderer(lambda lo, hi: build_graph(params, lo, hi), V * world, bus_channels=2,
                                             rate=RATE, timer=timer, fuse=fuse)
         assert (renderer.lo, renderer.hi) == (rank * V, (rank + 1) * V)
@@ -493,6 +517,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             bus = step()
+        if timer:
+            timer.close()
         if pending is not None:
             pending.wait()
             pending = None
@@ -537,8 +563,8 @@ def main():
                             '(fused_steady_bus_kernel); constant-parameter Sine->LowPass|HighPass->[Gain]->SumBus takes it; other '
                             'oscillators, per-block (LFO) cutoff / gain rows and two-oscillator voices run the span walker in one '
                             'launch too (1.2-2.5 T voice-samples/s), anything else per-node kernels' if closed else 'span walker (fused_walk_kernel)',
-                    'launches': 'avg_launch_ms is the HIP-event time of every 8th launch of the timed steps (bracketing all of them '
-                                'cost the stream 12 %): one kernel per batch -- it adds its two voice tiles itself '
+                    'launches': 'avg_launch_ms = (one HIP event behind the last timed launch - one in front of the first) / launches: the '
+                                'per-step time on the GPU timeline, launch gaps included, nothing recorded between the launches; one kernel per batch -- it adds its two voice tiles itself '
                                 '(sig_bus::sum_tiles_in_workgroup) -- plus steady_prep_kernel on the calls where the per-voice '
                                 "constants change; the kernel's duration under the profiler is in profiles/*_kernel_stats.csv"})
             else:
@@ -571,23 +597,47 @@ def main():
 
     by_batch = None
     if world == 1 and not args.single_mode and not args.materialised:
-        # the same schedule at other batch lengths (BASELINE.md's throughput mode is K = 256), clocks already settled
+        # the same schedule at other batch lengths, clocks already settled.  K = 256 is SURVEY.md 8d's "throughput mode": a leg of its
+        # own with a roofline entry (region-timed like the headline)
         from signals_amd.engine import BatchRenderer
         by_batch = {}
         for k in (256, 1024, 8192, 16384):                  # (the longer ones: two and four waves per SIMD instead of one)
             if k == K:
                 continue
-            r = BatchRenderer(build_graph(params, 0, V), 2, RATE)
+            timer = KernelTimer(region=True)
+            r = BatchRenderer(build_graph(params, 0, V), 2, RATE, timer=timer)
             pos, reps = 0, max(20, 200 * 1024 // max(k, 1024))
-            for _ in range(10):
+            wrap = max(1, int(2.0 ** 26 / 1760.0 * RATE) // (N * k) - 1)         # stay inside the closed form's phase range
+            for i in range(10):
                 r.render(pos, N, k); pos += N * k
             torch.cuda.synchronize()
+            timer.reset()
             t0 = time.perf_counter()
-            for _ in range(reps):
+            for i in range(reps):
+                if i % wrap == 0:
+                    pos = 0
                 r.render(pos, N, k); pos += N * k
+            timer.close()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
-            by_batch[str(k)] = {'Msamples_per_s': V * N * k / dt / 1e6, 'ms_per_step': dt * 1e3}
+            entry = {'Msamples_per_s': V * N * k / dt / 1e6, 'ms_per_step': dt * 1e3}
+            summ = timer.summary()
+            if k == 256 and summ:
+                plan = _native.fused_voice_bus_plan('Sine', N * k, V, N, k, 100)
+                live = closed_form_live_fraction(params, 0, V, N, plan['voices_per_lane'])
+                ops = 1.0 + 2 + 3.0 * live + 17.0 * 2 / (16 * plan['voices_per_lane'])
+                dom = max(summ, key=lambda n_: summ[n_]['ms'])
+                avg_ms = summ[dom]['ms'] / summ[dom]['calls']
+                ach = ops * V * N * k / (avg_ms * 1e-3) / 1e12
+                entry['roofline'] = {'bound': 'valu_f64', 'kernel': dom, 'achieved': ach, 'peak': F64_VALU_PEAK, 'unit': 'T f64-instr-lanes/s',
+                                     'frac': ach / F64_VALU_PEAK, 'f64_ops_per_voice_sample': ops, 'avg_launch_ms': avg_ms,
+                                     'voices_per_lane': plan['voices_per_lane'], 'blocks_per_lane': plan['blocks_per_lane'],
+                                     'homogeneous_live_fraction': live,
+                                     'note': 'SURVEY.md 8d throughput mode (K = 256): 1024 waves of ONE block each -- a wave walks its 256 rows '
+                                             'serially (~100 ns per row at 4 voices per lane: one wave per SIMD, nothing to overlap the dependent '
+                                             'chains with) behind a per-span set-up of ~10 us; the launch is latency-bound, not issue-bound '
+                                             '(tools/time_fused_geom.py: every geometry of the same launch, DESIGN.md 5)'}
+            by_batch[str(k)] = entry
 
     latency = None
     if world == 1 and not args.single_mode:
@@ -620,6 +670,7 @@ def main():
     if world == 1 and not args.single_mode and not args.no_configs and not args.no_cpu_baseline:
         configs = {name: run_config(name) for name in ('C3', 'C5')}
         configs['C2_modulated'] = run_modulated()
+        configs['voice_programs'] = run_programs()
 
     if rank == 0:
         def describe(fused):

@@ -198,8 +198,8 @@ int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t posi
  * for block b, rows contiguous: row b of a per-voice parameter starts at + b * voices, of a broadcast one at + b).
  * The row-by-row span walker (the next block's warm-up chain runs with the next block's design) -- except a Sine voice
  * under a bus (sig_fused_voice_bus_rows), which keeps the closed form of sig_fused_voice_bus: the filter, its response at the
- * voice's frequency, T_c and the decay bound per (block, voice) from a prep launch, the steady-state recurrence re-seeded at every
- * block's first row (workspace: sig_fused_voice_bus_rows_workspace bytes).  gain may be NULL; bus_channels 1 or 2.  hertz and phase stay one row here (sig_fused_*_fm below takes rows for them too). */
+ * voice's frequency, T_c and the decay bound derived per (block, voice) inside the launch, the steady-state recurrence re-seeded
+ * at every block's first row.  gain may be NULL; bus_channels 1 or 2.  hertz and phase stay one row here (sig_fused_*_fm below takes rows for them too). */
 int sig_fused_osc_biquad_rows(int osc_kind, int filt_type, int32_t rate, int64_t position,
                               int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
                               const double* hertz, int32_t hertz_stride, const double* phase, int32_t phase_stride,
@@ -330,9 +330,6 @@ int sig_fused_osc_biquad_mix(int osc_kind, int filt_type, int32_t rate, int64_t 
  * constants of the closed form (steady-state sinusoid + homogeneous transient per cold-started block; voices it does
  * not cover are walked row by row in the same launch) into the tail of the workspace.  Deterministic; no atomics. */
 int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels);
-/* ... of sig_fused_voice_bus_rows: the same plus, when the cutoff is read per block (cutoff_rows > 1), the closed form's
- * per-(block, voice) filter constants (10 doubles each). */
-int64_t sig_fused_voice_bus_rows_workspace(int32_t voices, int64_t rows, int32_t bus_channels, int32_t nblocks, int32_t cutoff_rows);
 /* sig_fused_voice_bus restricted to the row-by-row span walker (never the Sine closed form).  The closed form, like
  * the walker's incremental Sine phase, holds while |t| = |frame / rate * hertz + phase| < 2^26 cycles (past that the
  * reference's own rounding of t, which neither reproduces, approaches the 1e-6 bar): a wave with a voice beyond it is

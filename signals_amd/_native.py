@@ -33,7 +33,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
            'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
-           'sig_voice_program', 'sig_voice_program_set_tuning', 'sig_fused_voice_bus_rows_workspace')
+           'sig_voice_program', 'sig_voice_program_set_tuning')
 
 
 class NativeError(RuntimeError):
@@ -121,8 +121,6 @@ def lib() -> ctypes.CDLL:
                                            dp, i32, dp, i32, dp, i32, dp, i32, vp, i64, vp, vp]
         L.sig_fused_voice_bus_workspace.restype = ctypes.c_int64
         L.sig_fused_voice_bus_workspace.argtypes = [i32, i64, i32]
-        L.sig_fused_voice_bus_rows_workspace.restype = ctypes.c_int64
-        L.sig_fused_voice_bus_rows_workspace.argtypes = [i32, i64, i32, i32, i32]
         L.sig_fused_voice_bus.restype = ctypes.c_int
         L.sig_fused_voice_bus.argtypes = [ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                           dp, i32, dp, i32, dp, i32, dp, i32, dp, i64, i32, vp, vp, i64, vp, vp]
@@ -747,7 +745,7 @@ def fused_rows(kind: str, btype: str, rate: int, position: int, block_frames: in
         bp, bld = bus_gains.data_ptr(), bus_gains.stride(0)
     elif C != 1:
         raise NativeError('a bus without gains is mono')
-    need = lib().sig_fused_voice_bus_rows_workspace(voices, rows, C, nblocks, crows)
+    need = lib().sig_fused_voice_bus_workspace(voices, rows, C)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need // 8, dtype=torch.float64, device=out.device)
     if pargs is not None:

@@ -457,10 +457,6 @@ void fused_walk_kernel(FusedArgs a, BusArgs bus)
 // block (c = min(ctx, position)), and the decay bound.
 enum { SC_NA1, SC_NA2, SC_SCALE, SC_K2C, SC_ST, SC_CT, SC_HRE, SC_HIM, SC_ND, SC_T, SC_T0 = SC_T + 4, kSteadyConsts = SC_T0 + 4 };
 
-// ... and, where the cutoff (and the gain) is read per block (an LFO sweep: forward_at_block_rate, chain/__init__.py:305-306;
-// fx.py:127-129), what depends on the filter per (block, voice): [kRowConsts][K][voices], made by steady_prep_rows_kernel
-enum { RC_NA1, RC_NA2, RC_SCALE, RC_HRE, RC_HIM, RC_ND, RC_T, kRowConsts = RC_T + 4 };
-
 // does the steady kernel take the wave of voices [v0, v0 + vpt) x 64 lanes for the span starting at frame p0?
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb) {
     const double q_first = (double)p0 / a.rate, q_last = (double)(p0 + (int64_t)nb * a.N - 1) / a.rate;
@@ -487,26 +483,6 @@ __global__ __launch_bounds__(256) void steady_prep_kernel(FusedArgs a, double* _
     put(SC_HRE, c.hre); put(SC_HIM, c.him); put(SC_ND, c.nd);
     put(SC_T + 0, c.T.a); put(SC_T + 1, c.T.b); put(SC_T + 2, c.T.c); put(SC_T + 3, c.T.d);
     put(SC_T0 + 0, c.T0.a); put(SC_T0 + 1, c.T0.b); put(SC_T0 + 2, c.T0.c); put(SC_T0 + 3, c.T0.d);
-}
-
-// one thread per (block, voice): the filter of that block (cutoff row b, gain row b or the one gain row), its response at the
-// voice's frequency, T_c for the block's context (only the launch's first block can have a short one) and the decay bound
-__global__ __launch_bounds__(256) void steady_prep_rows_kernel(FusedArgs a, double* __restrict__ rc)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)a.K * a.voices) return;
-    const int64_t b = idx / a.voices;
-    const int v = (int)(idx - b * a.voices);
-    const double cutoff = a.cutoff[(a.cutoff_rows > 1 ? b * (int64_t)(a.cs ? a.voices : 1) : 0) + (int64_t)v * a.cs];
-    const double gain = a.gain ? a.gain[(a.gain_rows > 1 ? b * (int64_t)(a.gs ? a.voices : 1) : 0) + (int64_t)v * a.gs] : 1.0;
-    const int64_t p_b = a.position + b * a.N;
-    const int c_b = (int)((p_b < (int64_t)a.ctx) ? p_b : (int64_t)a.ctx);
-    const SteadyVoice c = steady_constants_of<true>(a, v, cutoff, gain, c_b);
-    if (!c.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
-    const int64_t plane = (int64_t)a.K * a.voices;
-    auto put = [&](int k, double x) { rc[(int64_t)k * plane + idx] = x; };
-    put(RC_NA1, c.na1); put(RC_NA2, c.na2); put(RC_SCALE, c.scale); put(RC_HRE, c.hre); put(RC_HIM, c.him); put(RC_ND, c.nd);
-    put(RC_T + 0, c.T0.a); put(RC_T + 1, c.T0.b); put(RC_T + 2, c.T0.c); put(RC_T + 3, c.T0.d);
 }
 
 // The rare waves the closed form does not take (a voice below ~8 Hz, above rate/4 or past 2^26 cycles), done inside the
@@ -544,15 +520,19 @@ __device__ __forceinline__ void steady_fallback_span(const FusedArgs& a, const B
                 const int v = live ? v0 + i : vc;
                 const double t = q * a.hertz[(int64_t)v * a.hs] + (a.phase ? a.phase[(int64_t)v * a.ps] : 0.0);
                 const double x = (double)sig_osc::osc_sine_f32(t);
-                const double* rc = a.steady_rows;                                  // per-block cutoff rows: the block's own filter
-                const int64_t at = (b_first + bi) * (int64_t)a.voices + v, plane = (int64_t)a.K * a.voices;
-                const double na1 = rc ? rc[RC_NA1 * plane + at] : sc[(int64_t)SC_NA1 * a.voices + v];
-                const double na2 = rc ? rc[RC_NA2 * plane + at] : sc[(int64_t)SC_NA2 * a.voices + v];
+                double na1 = sc[(int64_t)SC_NA1 * a.voices + v], na2 = sc[(int64_t)SC_NA2 * a.voices + v];
+                double scale = live ? sc[(int64_t)SC_SCALE * a.voices + v] : 0.0;
+                if (a.cutoff_rows > 1) {                                       // per-block cutoff rows: the block's own design (wave-uniform branch)
+                    Biquad qd;
+                    design_butter2(a.type, a.cutoff[(b_first + bi) * (int64_t)(a.cs ? a.voices : 1) + (int64_t)v * a.cs], a.rate, qd);
+                    na1 = -qd.a1; na2 = -qd.a2;
+                    scale = live ? qd.b0 : 0.0;
+                    if (a.gain && a.gain_rows == 1) scale *= a.gain[(int64_t)v * a.gs];
+                }
                 const double y = x + z0[i];
                 z0[i] = fma(na1, y, fma(s2, x, z1[i]));
                 z1[i] = fma(na2, y, x);
-                double scale = live ? (rc ? rc[RC_SCALE * plane + at] : sc[(int64_t)SC_SCALE * a.voices + v]) : 0.0;
-                if (!rc && a.gain_rows > 1) scale *= a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];   // per-block gain rows (the constants then hold b0 only)
+                if (a.gain_rows > 1) scale *= a.gain[(b_first + bi) * (int64_t)(a.gs ? a.voices : 1) + (int64_t)v * a.gs];   // per-block gain rows (the constants then hold b0 only)
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) acc[ch] = fma(bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale, y, acc[ch]);
             }
@@ -594,8 +574,8 @@ template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ?
 
 // GROWS: the gain is read per block (a tremolo: sig_fused_voice_bus_rows with rows for the gain only); the constants then hold
 // b0 alone and the bus weights are rebuilt at every block's first row
-// CROWS: the cutoff (and possibly the gain) is read per block: the filter, its response H, T_c and the decay bound come from
-// the per-(block, voice) constants, the steady-state recurrence is re-seeded at every block's first row with that block's H
+// CROWS: the cutoff (and possibly the gain) is read per block: the filter, its response H, T_c and the decay bound are derived
+// at every block's first row from that block's rows, the steady-state recurrence is re-seeded at every block's first row with that block's H
 // (the oscillator itself runs on: the phase of the row is recomputed from the reference's own t, two sines per voice and block)
 template <int VPT, int C, bool GROWS, bool CROWS = false>
 __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
@@ -677,6 +657,14 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
         if (!capped) {                                                         // wave-uniform
             steady_fallback_span<VPT, C>(a, bus, tile, lane, vt, b_first, nb, v0);
             return;
+        }
+    }
+    [[maybe_unused]] OscPart osc[CROWS ? VPT : 1];                             // CROWS: what the per-block constants need of the oscillator (once per span)
+    if constexpr (CROWS) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int v = (v0 + i < a.voices) ? v0 + i : vc;
+            osc[i] = steady_osc_part(a.type, a.hertz[(int64_t)v * a.hs], a.rate, a.ctx);
         }
     }
     double z0h[LC], z1h[LC];
@@ -789,34 +777,49 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
         const bool first = (b_first + bi == 0);
         const int tk = first ? SC_T0 : SC_T;
         const int c = first ? (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx) : a.ctx;
-        const double* tbase = sc + (int64_t)tk * a.voices;                     // T_c of voice v at tbase[k * tstride + v]
-        int64_t tstride = a.voices;
         if constexpr (CROWS) {
-            // this block's filter: coefficients, bus weights, the steady-state seeds from its H, the decay bound per slot
-            const double* rc = a.steady_rows;
-            const int64_t plane = (int64_t)a.K * a.voices, at0 = (b_first + bi) * (int64_t)a.voices;
+            // this block's filter, derived here from cutoff row b (and gain row b): coefficients, bus weights, the steady-state
+            // seeds from its H at the voice's frequency, T_c for the block's context and the decay bound per slot.  ~300 f64
+            // operations per voice and block (steady_block_constants) against ~1100 for the block's 256 rows -- and no round trip of 80 bytes per
+            // (block, voice) through HBM, which a prep launch would cost (measured: 31 us + 29 us per 1024-block batch)
+            const int64_t blk = b_first + bi;
             const double q_b = (double)(p0 + (int64_t)bi * a.N) / a.rate;
+            // every load of the block first, all voices side by side: the rows of block b come from HBM, and one voice after
+            // the other (each voice's constants end in a loop) their latencies added up to 20 us per block
+            double cut_i[VPT], gain_i[VPT];                                    // (the block-invariant rows -- pan, hertz, phase -- sit in the caches)
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int v = (v0 + i < a.voices) ? v0 + i : vc;
+                cut_i[i] = a.cutoff[(a.cutoff_rows > 1 ? blk * (int64_t)(a.cs ? a.voices : 1) : 0) + (int64_t)v * a.cs];
+                gain_i[i] = a.gain ? a.gain[(a.gain_rows > 1 ? blk * (int64_t)(a.gs ? a.voices : 1) : 0) + (int64_t)v * a.gs] : 1.0;
+            }
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 const bool live = v0 + i < a.voices;
                 const int v = live ? v0 + i : vc;
-                auto row = [&](int k) { return rc[(int64_t)k * plane + at0 + v]; };
-                const double na1_i = row(RC_NA1);
-                if (i < LC) { na1[i < LC ? i : 0] = na1_i; na2[i < LC ? i : 0] = row(RC_NA2); }
-                if (live && na1_i != na1_i && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
-                const double scale = row(RC_SCALE);
+                const double cutoff = cut_i[i], gain = gain_i[i];
+                const double hz_v = a.hertz[(int64_t)v * a.hs], ph_v = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
+                // the oscillator's part is kept per voice for c = ctx; the launch's first block may have a shorter context
+                OscPart op = osc[i];
+                if (__builtin_expect(c != a.ctx, 0)) op = steady_osc_part(a.type, hz_v, a.rate, c);      // (wave-uniform, the first block of a stream only)
+                const double ct_i = op.ct, st_i = op.st;
+                const BlockVoice cv = steady_block_constants(a.type, a.rate, cutoff, gain, op, c);
+                if (i < LC) { na1[i < LC ? i : 0] = cv.na1; na2[i < LC ? i : 0] = cv.na2; }
+                if (live && !cv.ok && a.status) atomicOr(a.status, SIG_STATUS_BAD_CUTOFF);
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * scale : scale) : 0.0;
-                const double hz = a.hertz[(int64_t)v * a.hs], ph = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
-                const double t_first = q_b * hz + ph;                          // osc.py:32
+                for (int ch = 0; ch < C; ++ch) wt[ch][i] = live ? (bus.pan ? bus.pan[ch * bus.pan_ld + v] * cv.scale : cv.scale) : 0.0;
+                const double t_first = q_b * hz_v + ph_v;                      // osc.py:32
                 const double f0 = t_first - rint(t_first);
                 const double ur = sin2pi(f0 + 0.25), ui = sin2pi(f0);
-                const double hre = row(RC_HRE), him = row(RC_HIM);
-                const double wr = fma(hre, ur, -(him * ui)), wi = fma(hre, ui, him * ur);
+                const double wr = fma(cv.hre, ur, -(cv.him * ui)), wi = fma(cv.hre, ui, cv.him * ur);
                 yb[i] = wi;
-                ya[i] = fma(wi, sc[(int64_t)SC_CT * a.voices + v], -(wr * sc[(int64_t)SC_ST * a.voices + v]));
-                const double nd = row(RC_ND);
-                nd_total[i] = (live && nd < (double)kNeverDrops) ? (int)nd : (live ? kNeverDrops : 0);
+                ya[i] = fma(wi, ct_i, -(wr * st_i));
+                if (i < LC) {                                                  // the homogeneous state at the block's first row (zeroed below where the slot has none)
+                    const double dss = fma(k2c[i], yb[i], -ya[i]) - yb[i];      // yss_{p+1} - yss_p
+                    z0h[i < LC ? i : 0] = fma(cv.T.a, yb[i], cv.T.b * dss);
+                    z1h[i < LC ? i : 0] = fma(cv.T.c, yb[i], cv.T.d * dss);
+                }
+                nd_total[i] = (live && cv.nd < (double)kNeverDrops) ? (int)cv.nd : (live ? kNeverDrops : 0);
             }
 #pragma unroll
             for (int d = 1; d < SIG_WAVE; d <<= 1) {
@@ -828,8 +831,6 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
             }
 #pragma unroll
             for (int i = 0; i < VPT; ++i) nd_total[i] = __builtin_amdgcn_readfirstlane(nd_total[i]);
-            tbase = rc + (int64_t)RC_T * plane + at0;
-            tstride = plane;
         }
         int drop_at[LC];                                                       // row of the block from which slot i is dropped
 #pragma unroll
@@ -837,10 +838,12 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
             drop_at[i] = (nd_total[i] > c) ? nd_total[i] - c : 0;              // wave-uniform
             if (drop_at[i] > 0) {
                 const int v = (v0 + i < a.voices) ? v0 + i : vc;
-                const double* t = tbase + v;
                 const double dss = fma(k2c[i], yb[i], -ya[i]) - yb[i];          // yss_{p+1} - yss_p
-                z0h[i] = fma(t[0], yb[i], t[tstride] * dss);
-                z1h[i] = fma(t[2 * tstride], yb[i], t[3 * tstride] * dss);
+                if constexpr (!CROWS) {                                       // (CROWS: made with the block's constants above)
+                    const double* t = sc + (int64_t)tk * a.voices + v;
+                    z0h[i] = fma(t[0], yb[i], t[a.voices] * dss);
+                    z1h[i] = fma(t[2 * (int64_t)a.voices], yb[i], t[3 * (int64_t)a.voices] * dss);
+                }
             } else {
                 z0h[i] = 0.0; z1h[i] = 0.0;
             }
@@ -886,7 +889,7 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
 }
 
 template <int VPT, int C, bool GROWS = false, bool CROWS = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SteadyOcc<VPT>::waves, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CROWS ? 1 : SteadyOcc<VPT>::waves, 8)))
 void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     __shared__ double lds[4][kPairs * kTileStride];
@@ -897,13 +900,10 @@ void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 }
 
 // workspace of sig_fused_voice_bus: [tile partials, worst case one tile per 64 voices][steady constants]
-// ( + [per-(block, voice) constants] for sig_fused_voice_bus_rows with per-block cutoff rows: sig_fused_voice_bus_rows_workspace)
 int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
     return (int64_t)((voices + SIG_WAVE - 1) / SIG_WAVE) * rows * bus_channels;       // in doubles
 }
-int64_t steady_rows_offset(int voices, int64_t rows, int bus_channels) {
-    return steady_consts_offset(voices, rows, bus_channels) + (int64_t)kSteadyConsts * voices;
-}
+
 
 // Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
 // _STEADY, _SCAN: read ONCE, when the first launch asks) and tests set them through sig_fused_set_tuning.
@@ -976,6 +976,9 @@ int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_
             BusPlan plan = plan_voice_bus(a, KIND);
             if (plan.steady) {
                 if (plan.vpt > 8) plan.vpt = 8;
+                // per-block constants: 4 voices per lane (at 8 the per-span oscillator parts push the kernel past 512 registers, and
+                // the spills around every block's set-up cost 20 us of scratch round trips per block); tuning hook: as forced
+                if (!gain_only && plan.vpt > 4 && tuning().vpt == 0) plan.vpt = 4;
                 a.span = plan.span;
                 a.steady = 1;
                 // a swept cutoff (with or without a tremolo): per-(block, voice) filter constants; a tremolo alone: the bus
@@ -1055,12 +1058,7 @@ int launch_steady(FusedArgs& a, BusArgs& bus, int vpt, float* out, int64_t out_l
     a.steady_consts = consts;
     if (!(a.consts_ext && a.consts_ready))
         steady_prep_kernel<GAIN><<<(a.voices + 255) / 256, 256, 0, stream>>>(a, consts);
-    if constexpr (CROWS) {
-        double* rc = bus.partials + steady_rows_offset(a.voices, bus.rows, C);
-        const int64_t n = (int64_t)a.K * a.voices;
-        steady_prep_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, rc);
-        a.steady_rows = rc;
-    }
+
     a.voice_tiles = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -1546,12 +1544,6 @@ extern "C" int sig_fused_set_tuning(int32_t voices_per_lane, int32_t blocks_per_
     t.tile_sum_kernel = (closed_form == 2) ? 1 : 0;
     t.mix_f32 = (closed_form == 3) ? 1 : 0;                                    // 3: closed form on, the MixMatrix sink on v_mfma_f32_32x32x2_f32
     return 0;
-}
-
-extern "C" int64_t sig_fused_voice_bus_rows_workspace(int32_t voices, int64_t rows, int32_t bus_channels, int32_t nblocks, int32_t cutoff_rows)
-{
-    const int64_t base = steady_rows_offset(voices, rows, bus_channels);
-    return (base + (cutoff_rows > 1 ? (int64_t)kRowConsts * nblocks * voices : 0)) * (int64_t)sizeof(double);
 }
 
 extern "C" int64_t sig_fused_voice_bus_workspace(int32_t voices, int64_t rows, int32_t bus_channels)

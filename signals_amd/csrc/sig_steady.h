@@ -20,7 +20,6 @@ struct FusedArgs {
     int span = 1;                            // consecutive blocks per lane (> 1 needs N >= ctx)
     int steady = 0;                          // Sine + bus: waves passing steady_wave() are done by fused_steady_bus_kernel
     const double* steady_consts = nullptr;   // its per-voice constants (steady_prep_kernel)
-    const double* steady_rows = nullptr;     // ... per (block, voice) where the cutoff (and the gain) is read per block: [kRowConsts][K][voices]
     double* consts_ext = nullptr;            // caller-held buffer for them (sig_fused_voice_bus_prepared), else the workspace tail
     int consts_ready = 0;                    // the caller vouches that consts_ext already holds them: no prep launch
     int force_walk = 0;                      // sig_fused_voice_bus_walk: never the closed form
@@ -129,6 +128,94 @@ __device__ __forceinline__ SteadyVoice steady_constants(const FusedArgs& a, int 
 {
     const int c0 = (int)((a.position < (int64_t)a.ctx) ? a.position : (int64_t)a.ctx);
     return steady_constants_of<GAIN>(a, v, a.cutoff[(int64_t)v * a.cs], GAIN ? a.gain[(int64_t)v * a.gs] : 1.0, c0);
+}
+
+// The closed form's constants for ONE block of a voice whose cutoff (and gain) is read per block (fused_steady_bus_kernel<..,
+// CROWS>), in two parts.  What depends on the oscillator only is made once per span (OscPart: e^{j theta}, alpha / beta of the
+// map from (yss, dss) to the complex amplitude, and e^{-j c theta} / N(e^{-j theta}) for the block context c, N the numerator of
+// H); what depends on the block's filter per block (steady_block_constants): a light tangent (the argument is pi Wn / 2, Wn in
+// (0, 1): no Payne-Hanek reduction), H = N / D and 1 / H = D / N from ONE reciprocal, the decay bound through v_log_f32 with
+// two rows of margin -- three f64 divisions and ~350 instructions instead of nine and ~1500 (steady_constants_of), the same
+// values to rounding (the same tests cover both).
+struct OscPart { double ct, st, beta, enr, eni; };                            // beta = 1 / sin(theta); (enr, eni) = e^{-j c theta} / N
+struct BlockVoice { bool ok; double na1, na2, scale, hre, him; M2 T; double nd; };
+
+__device__ __forceinline__ OscPart steady_osc_part(int type, double hertz, double rate, int c)
+{
+    using sig_biquad::Cx; using sig_biquad::cx_mul; using sig_biquad::cx_div;
+    const double d = hertz / rate, dr = d - rint(d);
+    OscPart o;
+    o.st = sin2pi(dr); o.ct = sin2pi(dr + 0.25);
+    o.beta = 1.0 / o.st;
+    const double s2 = (type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
+    const Cx z = {o.ct, -o.st}, z2 = cx_mul(z, z);
+    const Cx N = {1.0 + s2 * z.re + z2.re, s2 * z.im + z2.im};
+    const double cf = (double)c * dr;
+    const Cx E = cx_div({sin2pi(cf + 0.25), -sin2pi(cf)}, N);
+    o.enr = E.re; o.eni = E.im;
+    return o;
+}
+
+__device__ __forceinline__ BlockVoice steady_block_constants(int type, double rate, double cutoff, double gain, const OscPart& o, int c)
+{
+    using sig_biquad::Cx; using sig_biquad::cx_mul;
+    BlockVoice r;
+    double wn = cutoff / (rate * 0.5);
+    wn = (wn < 0.0) ? 0.0 : ((wn > 1.0) ? 1.0 : wn);
+    r.ok = (wn > 0.0 && wn < 1.0);                                             // scipy raises otherwise (NaN too)
+    // k = tan(pi Wn / 2) = sn / cs: with den = cs^2 + sqrt2 sn cs + sn^2 the coefficients need ONE division
+    //   nrm = cs^2 / den,  k^2 nrm = sn^2 / den,  a1 = 2 (sn^2 - cs^2) / den,  a2 = (cs^2 - sqrt2 sn cs + sn^2) / den
+    const double x = sig_biquad::kPi * wn * 0.5;
+    const double xc = (1.5707963267948966 - x) + 6.123233995736766e-17;
+    const double sn = sig_osc::sin_poly(x), cs = sig_osc::sin_poly(xc);
+    const double sn2 = sn * sn, cs2 = cs * cs, sc2 = sig_biquad::kSqrt2 * sn * cs;
+    const double iden = 1.0 / (cs2 + sc2 + sn2);
+    const double b0 = (type == SIG_FILT_LOWPASS) ? sn2 * iden : cs2 * iden;
+    double a1 = 2.0 * (sn2 - cs2) * iden, a2 = (cs2 - sc2 + sn2) * iden;
+    if (!r.ok) { a1 = a2 = __builtin_nan(""); }
+    const double s2 = (type == SIG_FILT_LOWPASS) ? 2.0 : -2.0;
+    const Cx z = {o.ct, -o.st};                                                // e^{-j theta}
+    const Cx z2 = {o.ct * o.ct - o.st * o.st, -2.0 * o.ct * o.st};
+    const Cx N = {1.0 + s2 * z.re + z2.re, s2 * z.im + z2.im}, D = {1.0 + a1 * z.re + a2 * z2.re, a1 * z.im + a2 * z2.im};
+    const double id = 1.0 / (D.re * D.re + D.im * D.im);
+    const Cx H = {(N.re * D.re + N.im * D.im) * id, (N.im * D.re - N.re * D.im) * id};
+    const Cx P = {H.re - 1.0, H.im};
+    const Cx Pe = cx_mul(P, {o.ct, o.st});
+    const Cx Q = {Pe.re - s2 + a1 * H.re, Pe.im + a1 * H.im};
+    const Cx E = cx_mul({o.enr, o.eni}, D);                                    // e^{-j c theta} / H = (e^{-j c theta} / N) D
+    const Cx PE = cx_mul(P, E), QE = cx_mul(Q, E);
+    const double alpha = (1.0 - o.ct) * o.beta;                               // 2 sin^2(theta / 2) / sin(theta)  (theta >= 1e-3: the difference keeps 10 digits)
+    const M2 Mss = {fma(PE.im, alpha, PE.re), PE.im * o.beta, fma(QE.im, alpha, QE.re), QE.im * o.beta};
+    M2 Ac;                                                                     // A^c by squaring
+    const M2 A1 = {-a1, 1.0, -a2, 0.0};
+    if (c == 100) {                                                            // the reference's context (fx.py:82-83): 100 = 64 + 32 + 4, straight-line
+        const M2 A2 = m2_mul(A1, A1), A4 = m2_mul(A2, A2), A8 = m2_mul(A4, A4), A16 = m2_mul(A8, A8), A32 = m2_mul(A16, A16);
+        Ac = m2_mul(m2_mul(m2_mul(A32, A32), A32), A4);
+    } else {
+        Ac = M2{1.0, 0.0, 0.0, 1.0};
+        M2 Ap = A1;
+        for (int e = c; e > 0; e >>= 1) {
+            if (e & 1) Ac = m2_mul(Ac, Ap);
+            Ap = m2_mul(Ap, Ap);
+        }
+    }
+    const M2 t = m2_mul(Ac, Mss);
+    r.T = M2{-t.a, -t.b, -t.c, -t.d};
+    r.nd = __builtin_inf();
+    {
+        const double d2 = a2 - 0.25 * a1 * a1;
+        if (r.ok && d2 > 0.0 && a2 > 0.0 && a2 < 1.0) {
+            const float dd = __builtin_sqrtf((float)d2);
+            const float f2 = (float)(1.0 + 0.25 * a1 * a1 + d2);
+            const float kappa = (f2 + __builtin_sqrtf(fmaxf(f2 * f2 - 4.0f * (float)d2, 0.0f))) * __builtin_amdgcn_rcpf(2.0f * dd);
+            const float amp = (float)b0 * kappa * __builtin_sqrtf((float)(P.re * P.re + P.im * P.im + Q.re * Q.re + Q.im * Q.im)) * 1.001f;
+            const float rows = (amp > (float)kHomogeneousTol)
+                ? (__log2f((float)kHomogeneousTol) - __log2f(amp)) * __builtin_amdgcn_rcpf(0.5f * __log2f((float)a2)) : 0.0f;
+            if (rows == rows) r.nd = (double)(ceilf(rows * 1.0001f) + 3.0f);   // (float roundings, approximate reciprocals: margin)
+        }
+    }
+    r.na1 = -a1; r.na2 = -a2; r.scale = b0 * gain; r.hre = H.re; r.him = H.im;
+    return r;
 }
 
 __device__ __forceinline__ int wave_max_int(int x) {

@@ -67,17 +67,29 @@ class NotBatchable(Exception):
 class KernelTimer:
     """Optional per-kernel HIP-event timing on the launch stream (bench.py's roofline leg)."""
 
-    def __init__(self, sample_every: int = 1):
+    def __init__(self, sample_every: int = 1, region: bool = False):
         """`sample_every` = n: only every n-th launch of a kernel is bracketed by events (an event pair between two
         launches drains the queue: bracketing every 200-us launch cost the stream 12 %); the summary's calls, time and
-        units then count the bracketed launches only, so its averages stay per launch"""
+        units then count the bracketed launches only, so its averages stay per launch.
+        `region`: ONE event in front of the first launch and one behind the last (`close()`): nothing between the launches, so
+        the stream runs exactly as it does untimed; the elapsed time is shared out evenly over the launches (for schedules
+        that are one launch per step -- the average then includes the gap between two launches, as the wall clock does)"""
         self.records: list[tuple[str, torch.cuda.Event, torch.cuda.Event, dict]] = []
         self.sample_every = max(1, int(sample_every))
+        self.region = region
         self._seen: dict[str, int] = {}
+        self._units: dict[str, int] = {}
+        self._start = self._stop = None
 
     def launch(self, name: str, fn: typing.Callable, **meta):
         n = self._seen.get(name, 0)
         self._seen[name] = n + 1
+        if self.region:
+            self._units[name] = self._units.get(name, 0) + meta.get('units', 0)
+            if self._start is None:
+                self._start = torch.cuda.Event(enable_timing=True)
+                self._start.record()
+            return fn()
         if n % self.sample_every:
             return fn()
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -87,9 +99,23 @@ class KernelTimer:
         self.records.append((name, start, stop, meta))
         return out
 
+    def close(self) -> None:
+        """region mode: the event behind the last launch"""
+        if self.region and self._start is not None and self._stop is None:
+            self._stop = torch.cuda.Event(enable_timing=True)
+            self._stop.record()
+
     def summary(self) -> dict[str, dict]:
         """call after a device sync"""
         acc: dict[str, dict] = {}
+        if self.region:
+            self.close()
+            if self._start is None:
+                return acc
+            total, launches = self._start.elapsed_time(self._stop), sum(self._seen.values())
+            for name, calls in self._seen.items():
+                acc[name] = {'calls': calls, 'ms': total * calls / launches, 'units': self._units.get(name, 0)}
+            return acc
         for name, start, stop, meta in self.records:
             e = acc.setdefault(name, {'calls': 0, 'ms': 0.0, 'units': 0})
             e['calls'] += 1
@@ -100,6 +126,8 @@ class KernelTimer:
     def reset(self):
         self.records.clear()
         self._seen.clear()
+        self._units.clear()
+        self._start = self._stop = None
 
 
 class _CapturedLaunches:
@@ -1356,10 +1384,6 @@ class _VoiceChain:
             if bus_c not in (1, 2):
                 return None
             swept = controls[2].shape[0] > 1                                    # the cutoff is read per block
-            if swept:
-                need = _native.lib().sig_fused_voice_bus_rows_workspace(v, rows, bus_c, K, controls[2].shape[0]) // 8
-                if o._workspace.numel() < need:
-                    o._workspace = torch.empty(need, dtype=CTRL_DTYPE, device=dev)
             if (self.kind == 'Sine' and self.pair is None and not self.fm and controls[2].shape[1] == v
                     and (swept or (controls[3] is not None and controls[3].shape[0] > 1 and controls[3].shape[1] == v))):
                 # a swept cutoff and / or a tremolo: sig_fused_voice_bus_rows keeps the closed form (per-block filter constants,
@@ -1441,7 +1465,7 @@ class _VoiceChain:
             # last frame puts the fastest voice past the limit, the span walker takes the whole launch instead.
             per_frame, ph_max = held[3]
             walk = self.kind == 'Sine' and ph_max + (position + rows) * per_frame >= _native.SINE_FAST_MAX_CYCLES
-            if o.timer is None:
+            if o.timer is None or o.timer.region:
                 # the per-batch host path: one pre-bound ctypes call (the binding's per-call validation cost more than the launch at
                 # 256 blocks per batch); bound per set of constants, i.e. while the parameter uploads are the same tensors
                 call = held[5] if len(held) > 5 else None
@@ -1449,6 +1473,8 @@ class _VoiceChain:
                     call = _native.FusedVoiceBusCall(self.kind, self.btype, rate, N, K, CONTEXT, v, ctl[0], ctl[1], ctl[2], ctl[3], pan_now,
                                                      bus_c, o._workspace, status, held[2])
                     o._steady_consts = held = (*held[:5], call)
+                if o.timer is not None:
+                    return o.timer.launch(bus_name, lambda: call(position, out, ready, walk), units=rows * v)
                 return call(position, out, ready, walk)
             return o._launch(bus_name, lambda: _native.fused_voice_bus(self.kind, self.btype, rate, position, N, K, CONTEXT, v,
                                                                        ctl[0], ctl[1], ctl[2], ctl[3], pan_now, out,
