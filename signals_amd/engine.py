@@ -837,7 +837,7 @@ class _Batch:
         if C not in (1, 2) or voices is None or (gains is not None and gains.shape[1] != voices):
             return None
         memo_keys = {k[0] for k in self._memo}
-        prog = _VoiceProgram.compile(self, src_port.sig, voices)
+        prog = _VoiceProgram.compile(self, src_port.sig, voices, min_nodes=1)
         if prog is None or any(n in memo_keys for n in prog.uses):
             return None
         if self.owner.fuse_program != 'always' and not prog.worthwhile():
@@ -1822,15 +1822,16 @@ class _VoiceProgram:
                          units=out.shape[0] * v)
 
     @classmethod
-    def compile(cls, batch: '_Batch', top: Emitter, voices: int):
-        """the program, or None when the graph is not one (or is a single kernel anyway)"""
+    def compile(cls, batch: '_Batch', top: Emitter, voices: int, min_nodes: int = 2):
+        """the program, or None when the graph is not one (or is a single kernel anyway: under a bus one node is enough, the
+        bus being the second -- `min_nodes`)"""
         if top is None or not top.get_state().enabled:
             return None
         try:
             prog = cls(batch, top, voices)
         except _NoProgram:
             return None
-        return prog if prog.kernel_nodes >= 2 else None
+        return prog if prog.kernel_nodes >= min_nodes else None
 
     def describe(self) -> str:
         return ','.join(op for op, *_ in self.code)

@@ -144,6 +144,33 @@ def test_shapes_beyond_the_fused_kernels_are_one_launch_and_match_the_oracle(whi
     assert maxerr(default, f32(ref)) < 1e-6 * scale, which
 
 
+@pytest.mark.parametrize('kind', ['Sawtooth', 'Sine', 'two'])
+def test_voices_without_a_filter_under_a_bus_are_one_launch(kind):
+    """SumBus(Gain(Osc)) / SumBus(Mix(Osc, Osc)): oscillator(s) and bus in one interpreted launch instead of an oscillator kernel
+    writing 4 B per voice-sample for the bus kernel to read back (osc.py:26-62, fx.py:35-46)"""
+    from oracle import chain_ref as R
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import KernelTimer
+    V, N = 200, 256
+    p = draw(V, 29)
+    first = 'Sawtooth' if kind == 'two' else kind
+    o, ro = mkosc(first, p['hertz'], p['phase']), R.Osc(first, R.Fixed(p['hertz']), R.Fixed(p['phase']))
+    if kind == 'two':
+        m = fx.Mix(); m.left = o; m.right = mkosc('Triangle', p['hertz2']); m.mix = fix(p['mix'])
+        o, ro = m, R.Binary('Mix', ro, R.Osc('Triangle', R.Fixed(p['hertz2'])), R.Fixed(p['mix']))
+    g = fx.Gain(); g.left = o; g.right = fix(p['gain'])
+    bus = ext.SumBus(); bus.input = g; bus.get_state().gains = np.ascontiguousarray(p['pan'])
+    batches = (2, 5)
+    want = (R.render_stream(R.Binary('Gain', ro, R.Fixed(p['gain'])), 7 * N, N, sum(batches), V)) @ p['pan'].T
+    timer = KernelTimer()
+    got = render_batches(bus, 2, 7 * N, N, batches, timer)
+    names = launches(timer)
+    assert all(n.startswith('voice_program_bus[') for n in names), names
+    assert maxerr(got, f32(want)) < 1e-6 * max(1.0, np.abs(want).max())
+    per_node = render_batches(bus, 2, 7 * N, N, batches, fuse_program=False)
+    assert maxerr(got, per_node) < 1e-6 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize('N', [32, 64, 100])
 def test_blocks_no_longer_than_the_context_are_batched(N):
     """cascades and block-rate FM with 32-, 64- and 100-frame blocks (dev.py:139-141: the sink takes whatever block size PortAudio

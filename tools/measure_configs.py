@@ -30,6 +30,20 @@ def c2m(V, K=1024):
     return cfg.c2_modulated_graph(cfg.c2_params(V), 'Sawtooth'), 2, 256, K, ALGO
 
 
+def c2s(V, K=4096):
+    """C2's Sine voices with a block-rate cutoff sweep + tremolo: the closed form with per-block filter constants, N = 256"""
+    return cfg.c2_modulated_graph(cfg.c2_params(V), 'Sine', vibrato=False), 2, 256, K, ALGO
+
+
+def vp(V, K=1024):
+    """a shape no fused kernel covers (RingMod of two filtered oscillators -> Gain -> SumBus): one interpreted launch, N = 256"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('time_voice_program', ROOT / 'tools' / 'time_voice_program.py')
+    tvp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tvp)
+    return tvp.shapes(V)['ringmod_of_two_filtered'](), 2, 256, K, ALGO
+
+
 def c5(V, K=256):
     """Sine -> LowPass -> MixMatrix(64x64), V = 4096, N = 256"""
     return cfg.c5_graph(cfg.c5_params(V)), V, 256, K, ALGO
@@ -71,3 +85,5 @@ if __name__ == '__main__':
     run('C3 saw->LP->LP->xADSR->bus', c3, 1024, steps)
     run('C5 sine->LP->MixMatrix', c5, 4096, steps)
     run('C2 voices with vibrato + cutoff sweep + tremolo', c2m, 1024, steps)
+    run('C2 Sine voices with cutoff sweep + tremolo', c2s, 1024, steps)
+    run('RingMod of two filtered oscillators (voice program)', vp, 1024, steps)

@@ -25,6 +25,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
     --kernel-trace --output-format csv -d $out/pmc_fused_SQ_issue -- $BENCH --steps 6 --warmup 2 --prewarm-ms 100 --no-kernel-timing > $out/pmc_fused_SQ_issue.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $out/pmc_fused_SQ_lds -- $BENCH --steps 6 --warmup 2 --prewarm-ms 100 --no-kernel-timing > $out/pmc_fused_SQ_lds.log 2>&1
+# the fused schedule at 256 blocks per batch (BASELINE's literal "1024 voices x 256 blocks"): one wave per block span
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_k256 -- $BENCH --steps 200 --warmup 20 --blocks 256 \
+    > $out/stats_k256.json 2> $out/stats_k256.err
 echo "SQ passes done"
 # BASELINE configs 3 and 5 (tools/measure_configs.py renders both through the engine's default schedule)
 CFG="python3 $root/tools/measure_configs.py 6"
