@@ -633,10 +633,10 @@ def main():
                                      'frac': ach / F64_VALU_PEAK, 'f64_ops_per_voice_sample': ops, 'avg_launch_ms': avg_ms,
                                      'voices_per_lane': plan['voices_per_lane'], 'blocks_per_lane': plan['blocks_per_lane'],
                                      'homogeneous_live_fraction': live,
-                                     'note': 'SURVEY.md 8d throughput mode (K = 256): 1024 waves of ONE block each -- a wave walks its 256 rows '
-                                             'serially (~100 ns per row at 4 voices per lane: one wave per SIMD, nothing to overlap the dependent '
-                                             'chains with) behind a per-span set-up of ~10 us; the launch is latency-bound, not issue-bound '
-                                             '(tools/time_fused_geom.py: every geometry of the same launch, DESIGN.md 5)'}
+                                     'note': 'SURVEY.md 8d throughput mode (K = 256): ONE round of 1024 waves of one block each, one per SIMD, '
+                                             'plus a launch per 67 M voice-samples; giving a block to 2 / 4 waves changes nothing (24.0 / 31.9 us '
+                                             'against 24.4), so the round is issue-bound already: ~13 us of arithmetic (12.5 us inside a long '
+                                             'batch) + launch and drain (tools/time_fused_geom.py, tools/time_k256.py, DESIGN.md 7)'}
             by_batch[str(k)] = entry
 
     latency = None
