@@ -134,7 +134,13 @@ __device__ __forceinline__ void vp_put(float2& v, const float (&y)[2]) { v = mak
 // state fits two waves per SIMD at two voices per lane, which the interpreter's scalar dispatch needs to hide its branches.
 // The full register file (four filters, four oscillators, eight parameters, four temporaries, every instruction) runs at one.
 template <bool SMALL> struct VpLimits {
-    static constexpr int NF = SMALL ? 2 : 4, NO = SMALL ? 3 : 4, NP = SMALL ? 4 : 8, NT = SMALL ? 1 : 4;
+#ifndef SIG_VP_S_NF
+#define SIG_VP_S_NF 2
+#define SIG_VP_S_NO 3
+#define SIG_VP_S_NP 4
+#define SIG_VP_S_NT 1
+#endif
+    static constexpr int NF = SMALL ? SIG_VP_S_NF : 4, NO = SMALL ? SIG_VP_S_NO : 4, NP = SMALL ? SIG_VP_S_NP : 8, NT = SMALL ? SIG_VP_S_NT : 4;
     static constexpr bool EXT = !SMALL;
 };
 
@@ -164,7 +170,7 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #pragma unroll
     for (int k = 0; k < kMaxIns; ++k) codev = (lane == k) ? a.code[k] : codev;
 
-    double acc[RG][VPT], T[NT][RG][VPT], pr[NP][VPT], ohz[NO][VPT], oph[NO][VPT];
+    double acc[RG][VPT], T[NT > 0 ? NT : 1][RG][VPT], pr[NP][VPT], ohz[NO][VPT], oph[NO][VPT];
     double z0[NF][VPT], z1[NF][VPT], w0[NF][VPT], w1[NF][VPT], na1[NF][VPT], na2[NF][VPT], fb0[NF][VPT], xa1[NF][VPT], xa2[NF][VPT];
     double s2[NF];
     double wt[CC][VPT];
@@ -366,8 +372,16 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
         double q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) q[r] = sig_readlane_f64(q_lane, (int)(n - qbase) + r);     // osc.py:32
+#ifdef SIG_VP_STATIC_CODE
+        // a specialised build: the program is a compile-time constant, the loop is unrolled and every switch below folds away
+        constexpr uint32_t kStatic[] = SIG_VP_STATIC_CODE;
+#pragma unroll
+        for (int pc = 0; pc < (int)(sizeof(kStatic) / sizeof(kStatic[0])); ++pc) {
+            const uint32_t w = kStatic[pc];
+#else
         for (int pc = 0; pc < a.n_ins; ++pc) {
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)codev, pc);
+#endif
             const int op = (int)(w & 31u), kind = (int)((w >> 5) & 7u), ia = (int)((w >> 8) & 15u), ib = (int)((w >> 12) & 15u),
                       ic = (int)((w >> 16) & 15u);
             switch (op) {

@@ -28,13 +28,14 @@ progs = {
 }
 for name, (code, depth) in progs.items():
     filters = [(cut, 'lp', i + 1) for i in range(depth)]
+    nt = 1 if any(op in ('Save', 'Load') for op, *_ in code) else 0
     hist = [] if depth < 2 else []
     for sink in ('bus', 'store'):
         def run():
             if sink == 'bus':
-                _native.voice_program(code, [(hz, ph)], [g], filters, 1, depth, 48000, 0, N, K, 100, V, 1 + K, hist, out, bus_gains=pan, bus=True, workspace=ws)
+                _native.voice_program(code, [(hz, ph)], [g], filters, nt, depth, 48000, 0, N, K, 100, V, 1 + K, hist, out, bus_gains=pan, bus=True, workspace=ws)
             else:
-                _native.voice_program(code, [(hz, ph)], [g], filters, 1, depth, 48000, 0, N, K, 100, V, 1 + K, hist, full)
+                _native.voice_program(code, [(hz, ph)], [g], filters, nt, depth, 48000, 0, N, K, 100, V, 1 + K, hist, full)
         for _ in range(3): run()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5): run()
