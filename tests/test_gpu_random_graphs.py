@@ -114,3 +114,63 @@ def test_random_graph_eager_vs_batched(seed):
         fused = BatchRenderer(node, channels, RATE).render(pos, N, K).cpu().numpy()
         scale = max(1.0, float(np.nanmax(np.abs(want)))) if np.isfinite(want).any() else 1.0
         assert maxerr(fused, want) < 1e-6 * scale, (seed, pos)
+
+
+PROGRAM_RUNS = {'renders': 0, 'with_program': 0, 'short_blocks': 0}
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_random_graph_voice_program_vs_eager(seed):
+    """the same random graphs with every per-voice sub-graph the compiler can express forced through the interpreted
+    launch (sig_voice_program; by default only where it is faster), continuing batches and a fresh mid-stream start, blocks
+    longer and SHORTER than the filter context -- against the eager pull path, the literal mirror of the reference's request
+    protocol and block cache (chain/__init__.py:266-303, :424-457)"""
+    from signals_amd import _native
+    from signals_amd.engine import BatchRenderer, KernelTimer, NotBatchable
+    b = Builder(seed)
+    ran = 0
+    # launch geometry: the heuristic (one voice per lane, one block per lane at this size), two voices per lane with spans of
+    # two blocks, one voice per lane with spans of three
+    _native.set_voice_program_tuning(*((0, 0), (2, 2), (1, 3))[seed % 3])
+    try:
+        _random_graph_program_case(b, seed, BatchRenderer, KernelTimer, NotBatchable)
+    finally:
+        _native.set_voice_program_tuning(0, 0)
+
+
+def _random_graph_program_case(b, seed, BatchRenderer, KernelTimer, NotBatchable):
+    ran = 0
+    for pos, N, batches in ((0, 128, (1, 2)), (1000, 256, (2, 1)), (0, 64, (3, 2, 1)), (640, 32, (4, 3))):
+        node, channels = b.build()
+        K = sum(batches)
+        want = stream(node, pos, N, K, channels)
+        node, channels = b.build()
+        timer = KernelTimer()
+        r = BatchRenderer(node, channels, RATE, fuse_program='always', timer=timer)
+        try:
+            parts, p = [], pos
+            for k in batches:
+                parts.append(r.render(p, N, k)); p += N * k
+        except NotBatchable:
+            assert N < 100, (seed, pos, N)                   # only short blocks may be refused (deep cascades, band filters: the eager path)
+            continue
+        got = torch.cat(parts).cpu().numpy()
+        ran += 1
+        names = set(timer.summary())
+        PROGRAM_RUNS['renders'] += 1
+        PROGRAM_RUNS['with_program'] += any(n.startswith('voice_program') for n in names)
+        PROGRAM_RUNS['short_blocks'] += N < 100
+        scale = max(1.0, float(np.nanmax(np.abs(want)))) if np.isfinite(want).any() else 1.0
+        assert got.shape == want.shape
+        assert maxerr(got, want) < 1e-6 * scale, (seed, pos, N)
+    assert ran >= 2
+
+
+def test_the_random_graphs_did_exercise_the_voice_program():
+    """(runs after the 48 seeds above) most of those graphs contain a sub-graph the interpreter takes, and a good share of
+    the short-block renders stayed in the batched engine"""
+    if PROGRAM_RUNS['renders'] == 0:
+        pytest.skip('the seeds did not run in this session')
+    print(PROGRAM_RUNS)
+    assert PROGRAM_RUNS['with_program'] >= PROGRAM_RUNS['renders'] // 2, PROGRAM_RUNS
+    assert PROGRAM_RUNS['short_blocks'] >= 24, PROGRAM_RUNS
