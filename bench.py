@@ -418,6 +418,10 @@ def run_programs(K: int = 1024, steps: int = 10) -> dict:
         fast, launches = tvp.rate(build, V, N, K, True, steps=steps)
         slow, _ = tvp.rate(build, V, N, K, False, steps=4)
         out['shapes'][name] = {'value': fast * 1e6, 'one_kernel_per_node': slow * 1e6, 'launches_us': launches}
+        # the same program as a kernel built for it (BatchRenderer(specialise=True): hipcc at the first render, then the disk cache)
+        spec, spec_launches = tvp.rate(build, V, N, K, 'always', steps=steps, specialise=True)
+        if any(k.endswith('*specialised') for k in spec_launches):
+            out['shapes'][name]['specialised'] = {'value': spec * 1e6, 'launches_us': spec_launches}
     return out
 
 

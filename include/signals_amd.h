@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SIG_ABI_VERSION 6
+#define SIG_ABI_VERSION 7
 
 enum { SIG_F32 = 0, SIG_F64 = 1 };
 
@@ -489,6 +489,26 @@ int sig_voice_program(const sig_voice_program_t* program, int32_t rate, int64_t 
 /* Tuning / test hook: force the voices per lane (1, 2; 0 = heuristic; ignored where the program does not fit the variant) and
  * the blocks per lane (0 = heuristic) of sig_voice_program.  Process-wide. */
 int sig_voice_program_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane);
+/* Introspection, no device work: the voices per lane (1 | 2) and blocks per lane sig_voice_program picks for a problem;
+ * store_aligned: bus_channels == 0 and `out` is 8-byte aligned with even voices and out_ld. */
+int sig_voice_program_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context, int32_t depth,
+                               int32_t bus_channels, int32_t store_aligned, int32_t* voices_per_lane, int32_t* blocks_per_lane);
+/* SPECIALISED kernels.  The interpreter's source (signals_amd/csrc/voice_program.hip) built once more as a gfx950 code object
+ * with ONE program as a compile-time constant -- macros SIG_VP_STATIC_CODE={words}, SIG_VP_S_NF / _NO / _NP / _NT / _EXT (the
+ * register file: filter, oscillator, parameter, temporary slots; Amp / ADSR / White enabled), SIG_VP_STATIC_VPT, SIG_VP_STATIC_C,
+ * SIG_VP_STATIC_WAVES; `hipcc --genco`, see signals_amd/specialise.py -- runs the same arithmetic as straight-line code (the
+ * dispatch loop unrolls, every switch folds: 1.5-1.7x the interpreter).  sig_voice_program_attach hands such an image to the
+ * library: it is loaded (hipModuleLoadData), asked what it was built for (its sig_vp_specialised_info kernel: the size of
+ * the argument block, voices per lane, sink, program words -- anything else than THIS library's and the program given is
+ * hipErrorInvalidImage) and from then on launched by sig_voice_program whenever it is called with the same words, slot counts
+ * (n_oscs, n_params, n_filters, n_temps of `program`; its row pointers are not read), voices per lane and bus_channels.
+ * A set-up call: allocates, launches and synchronises; not for a capturing stream.  sig_voice_program_use_attached(0) makes
+ * every launch use the interpreter again (test hook), sig_voice_program_detach_all unloads the images (no launch may be in
+ * flight).  sig_voice_program_args_size: sizeof of the kernels' argument block in this build. */
+int sig_voice_program_attach(const sig_voice_program_t* program, int32_t voices_per_lane, int32_t bus_channels, const void* image);
+int sig_voice_program_detach_all(void);
+int sig_voice_program_use_attached(int32_t on);
+int64_t sig_voice_program_args_size(void);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ OSC_KINDS = {'Sine': 0, 'Square': 1, 'Sawtooth': 2, 'Triangle': 3}
 FILT_TYPES = {'lp': 0, 'hp': 1, 'bp': 2, 'bs': 3}
 EW_OPS = {'Gain': 0, 'Mix': 1, 'RingMod': 2, 'Amp': 3}
 STATUS_BAD_CUTOFF = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 SINE_FAST_MAX_CYCLES = 2.0 ** 26     # sig_osc.h kSineFastMaxT: |t| up to which the fused Sine kernels advance the phase incrementally
 
 EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_coldstart', 'sig_elementwise', 'sig_sum_bus',
@@ -33,7 +33,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_cascade_bus', 'sig_fused_cascade_geometry', 'sig_fused_cascade_set_tuning',
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
            'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
-           'sig_voice_program', 'sig_voice_program_set_tuning')
+           'sig_voice_program', 'sig_voice_program_set_tuning', 'sig_voice_program_geometry', 'sig_voice_program_args_size',
+           'sig_voice_program_attach', 'sig_voice_program_detach_all', 'sig_voice_program_use_attached')
 
 
 class NativeError(RuntimeError):
@@ -188,6 +189,16 @@ def lib() -> ctypes.CDLL:
                                         dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_voice_program_set_tuning.restype = ctypes.c_int
         L.sig_voice_program_set_tuning.argtypes = [i32, i32]
+        L.sig_voice_program_geometry.restype = ctypes.c_int
+        L.sig_voice_program_geometry.argtypes = [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.sig_voice_program_args_size.restype = ctypes.c_int64
+        L.sig_voice_program_args_size.argtypes = []
+        L.sig_voice_program_attach.restype = ctypes.c_int
+        L.sig_voice_program_attach.argtypes = [ctypes.POINTER(VoiceProgramT), i32, i32, ctypes.c_char_p]
+        L.sig_voice_program_detach_all.restype = ctypes.c_int
+        L.sig_voice_program_detach_all.argtypes = []
+        L.sig_voice_program_use_attached.restype = ctypes.c_int
+        L.sig_voice_program_use_attached.argtypes = [i32]
         L.sig_fused_osc_pair_biquad.restype = ctypes.c_int
         L.sig_fused_osc_pair_biquad.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32, i64, i32, i32, i32, i32,
                                                 dp, i32, dp, i32, dp, i32, dp, i32, dp, i32,
@@ -1063,6 +1074,42 @@ def voice_program(code: list, oscs: list, params: list, filters: list, n_temps: 
                                    workspace.data_ptr() if workspace is not None else None, out.data_ptr(), out.stride(0),
                                    status.data_ptr() if status is not None else None, _stream(out)), 'sig_voice_program')
     return out
+
+
+def voice_program_words(code: list) -> list:
+    """the machine words of a program given as (op name, kind, a, b, c) tuples: op | kind << 5 | a << 8 | b << 12 | c << 16"""
+    return [VP_OPS[op] | (kind << 5) | (a << 8) | (b << 12) | (c << 16) for op, kind, a, b, c in code]
+
+
+def voice_program_geometry(voices: int, block_frames: int, nblocks: int, context: int, depth: int, bus_channels: int,
+                           store_aligned: bool) -> tuple:
+    """(voices per lane, blocks per lane) sig_voice_program picks for this problem (introspection, no device work)"""
+    vpt, span = ctypes.c_int32(0), ctypes.c_int32(0)
+    _check(lib().sig_voice_program_geometry(voices, block_frames, nblocks, context, depth, bus_channels, 1 if store_aligned else 0,
+                                            ctypes.byref(vpt), ctypes.byref(span)), 'sig_voice_program_geometry')
+    return vpt.value, span.value
+
+
+def voice_program_attach(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int,
+                         bus_channels: int, image: bytes) -> None:
+    """hand the library a specialised build of voice_program.hip for exactly this program (signals_amd/specialise.py): later
+    sig_voice_program calls with the same program, slot counts, voices per lane and sink launch it instead of the interpreter.
+    Loads the image, runs its self-description kernel and synchronises: a set-up call, not a render call."""
+    P = VoiceProgramT()
+    P.n_ins = len(code)
+    for k, (op, kind, a, b, c) in enumerate(code):
+        P.ins[k] = VpIns(VP_OPS[op], kind, a, b, c)
+    P.n_oscs, P.n_params, P.n_filters, P.n_temps = n_oscs, n_params, n_filters, n_temps
+    _check(lib().sig_voice_program_attach(ctypes.byref(P), voices_per_lane, bus_channels, image), 'sig_voice_program_attach')
+
+
+def voice_program_detach_all() -> None:
+    _check(lib().sig_voice_program_detach_all(), 'sig_voice_program_detach_all')
+
+
+def voice_program_use_attached(on: bool) -> None:
+    """test hook (process-wide): launch attached specialised kernels (default) or always the interpreter"""
+    _check(lib().sig_voice_program_use_attached(1 if on else 0), 'sig_voice_program_use_attached')
 
 
 def set_voice_program_tuning(voices_per_lane: int = 0, blocks_per_lane: int = 0) -> None:

@@ -31,7 +31,10 @@
 // Arithmetic: f64 throughout, exact per-row phase t = n / rate * hertz + phase (osc.py:32, one IEEE divide per row shared
 // by the wave), Butterworth design per block in-kernel (sig_biquad.h), b0-normalised DF2T recurrence (4 FMAs + 1).  No
 // float32 rounding between nodes: closer to the f64 reference than the per-node schedule; 1e-6 parity by test.
+#include <cstring>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "sig_adsr.h"
 #include "sig_biquad.h"
@@ -141,7 +144,11 @@ template <bool SMALL> struct VpLimits {
 #define SIG_VP_S_NT 1
 #endif
     static constexpr int NF = SMALL ? SIG_VP_S_NF : 4, NO = SMALL ? SIG_VP_S_NO : 4, NP = SMALL ? SIG_VP_S_NP : 8, NT = SMALL ? SIG_VP_S_NT : 4;
+#ifdef SIG_VP_S_EXT
+    static constexpr bool EXT = !SMALL || (SIG_VP_S_EXT != 0);
+#else
     static constexpr bool EXT = !SMALL;
+#endif
 };
 
 // C == 0: store (float) acc to a.out; C > 0: C bus channels into a.partials.  EXT: Amp, ADSR and White instructions.
@@ -623,7 +630,7 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #define SIG_VP_WAVES1 3
 #endif
 template <int VPT, bool SMALL, int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? (VPT == 1 ? SIG_VP_WAVES1 : SIG_VP_WAVES) : 1, 8))) void voice_program_kernel(VpArgs a)
+__device__ __forceinline__ void vp_kernel_body(const VpArgs& a)
 {
     constexpr bool BUS = C > 0;
     __shared__ double lds[BUS ? 4 : 1][BUS ? sig_bus::kPairs * kTileStride : 1];
@@ -635,8 +642,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? (VP
     }
 }
 
-struct VpTuning { int vpt = 0, span = 0; };
+#ifdef SIG_VP_STATIC_CODE
+// A SPECIALISED build of this file (signals_amd/specialise.py: hipcc --genco with the program, the exact register file, the
+// voices per lane and the sink as macros): one kernel, the same source as the interpreter with the program a compile-time
+// constant -- the dispatch loop unrolls and every switch folds.  Attached to the library with sig_voice_program_attach.
+}  // namespace
+extern "C" __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIG_VP_STATIC_WAVES, 8)))
+void sig_vp_specialised(VpArgs a) { vp_kernel_body<SIG_VP_STATIC_VPT, true, SIG_VP_STATIC_C>(a); }
+// what the attaching library checks before it trusts the image: the argument block's size and the program it was built for
+extern "C" __global__ void sig_vp_specialised_info(uint32_t* out)
+{
+    constexpr uint32_t code[] = SIG_VP_STATIC_CODE;
+    out[0] = (uint32_t)sizeof(VpArgs); out[1] = SIG_VP_STATIC_VPT; out[2] = SIG_VP_STATIC_C; out[3] = (uint32_t)(sizeof(code) / sizeof(code[0]));
+    for (unsigned k = 0; k < sizeof(code) / sizeof(code[0]); ++k) out[4 + k] = code[k];
+}
+#else
+template <int VPT, bool SMALL, int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMALL ? (VPT == 1 ? SIG_VP_WAVES1 : SIG_VP_WAVES) : 1, 8))) void voice_program_kernel(VpArgs a)
+{
+    vp_kernel_body<VPT, SMALL, C>(a);
+}
+
+struct VpTuning { int vpt = 0, span = 0, attached = 1; };
 VpTuning& vp_tuning() { static VpTuning t; return t; }
+
+// Specialised kernels attached at run time (sig_voice_program_attach): this file built once more for ONE program, found again
+// by the program's words, the slot counts, the voices per lane and the sink.  Entries are never removed while launches may be
+// in flight (detach is for tests and process exit); the list is short, a linear search costs less than the launch.
+struct VpSpecial { uint32_t code[kMaxIns]; int n_ins, n_oscs, n_params, n_filters, n_temps, vpt, C; hipModule_t mod; hipFunction_t fn; };
+std::vector<VpSpecial>& vp_specials() { static std::vector<VpSpecial> v; return v; }
+std::mutex& vp_specials_lock() { static std::mutex m; return m; }
+
+bool vp_encode(const sig_voice_program_t& P, uint32_t* code) {
+    for (int k = 0; k < P.n_ins; ++k) {
+        const sig_vp_ins& x = P.ins[k];
+        if (!(x.op >= SIG_VP_OSC && x.op <= SIG_VP_NOISE && x.kind >= 0 && x.kind <= 7 && x.a >= 0 && x.a <= 15 && x.b >= 0 && x.b <= 15 && x.c >= 0 && x.c <= 15))
+            return false;
+        code[k] = (uint32_t)x.op | ((uint32_t)x.kind << 5) | ((uint32_t)x.a << 8) | ((uint32_t)x.b << 12) | ((uint32_t)x.c << 16);
+    }
+    return true;
+}
+
+hipFunction_t vp_find_special(const VpArgs& a, const sig_voice_program_t& P, int vpt, int C) {
+    if (!vp_tuning().attached) return nullptr;
+    std::lock_guard<std::mutex> g(vp_specials_lock());
+    for (const VpSpecial& e : vp_specials())
+        if (e.n_ins == a.n_ins && e.vpt == vpt && e.C == C && e.n_oscs == P.n_oscs && e.n_params == P.n_params &&
+            e.n_filters == P.n_filters && e.n_temps == P.n_temps && memcmp(e.code, a.code, sizeof(uint32_t) * a.n_ins) == 0)
+            return e.fn;
+    return nullptr;
+}
 
 struct VpNeeds { int oscs, params, temps, filters; bool ext; };
 
@@ -683,6 +738,68 @@ extern "C" int sig_voice_program_set_tuning(int32_t voices_per_lane, int32_t blo
     return 0;
 }
 
+extern "C" int sig_voice_program_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context, int32_t depth,
+                                          int32_t bus_channels, int32_t store_aligned, int32_t* voices_per_lane, int32_t* blocks_per_lane)
+{
+    SIG_CHECK_ARG(voices >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && depth >= 0 && voices_per_lane && blocks_per_lane);
+    VpArgs a{};
+    a.voices = voices; a.N = block_frames; a.K = nblocks; a.ctx = context;
+    a.small = (depth > 0 && block_frames < context) ? 1 : 0;
+    double dummy = 0.0;
+    a.partials = bus_channels > 0 ? &dummy : nullptr;                          // (only asked whether there is a bus)
+    int vpt = 1, span = 1;
+    vp_geometry(a, store_aligned != 0, vpt, span);
+    *voices_per_lane = vpt; *blocks_per_lane = span;
+    return 0;
+}
+
+extern "C" int64_t sig_voice_program_args_size(void) { return (int64_t)sizeof(VpArgs); }
+
+extern "C" int sig_voice_program_use_attached(int32_t on) { vp_tuning().attached = on ? 1 : 0; return 0; }
+
+extern "C" int sig_voice_program_attach(const sig_voice_program_t* program, int32_t voices_per_lane, int32_t bus_channels,
+                                        const void* image)
+{
+    SIG_CHECK_ARG(program && image && (voices_per_lane == 1 || voices_per_lane == 2) && bus_channels >= 0 && bus_channels <= 2);
+    const sig_voice_program_t& P = *program;
+    SIG_CHECK_ARG(P.n_ins >= 1 && P.n_ins <= SIG_VP_MAX_INS);
+    VpSpecial e{};
+    SIG_CHECK_ARG(vp_encode(P, e.code));
+    e.n_ins = P.n_ins; e.n_oscs = P.n_oscs; e.n_params = P.n_params; e.n_filters = P.n_filters; e.n_temps = P.n_temps;
+    e.vpt = voices_per_lane; e.C = bus_channels;
+    hipError_t err = hipModuleLoadData(&e.mod, image);
+    if (err != hipSuccess) { (void)hipGetLastError(); return (int)err; }       // (not sticky: the caller's next HIP call must not inherit it)
+    hipFunction_t info = nullptr;
+    err = hipModuleGetFunction(&e.fn, e.mod, "sig_vp_specialised");
+    if (err == hipSuccess) err = hipModuleGetFunction(&info, e.mod, "sig_vp_specialised_info");
+    // the image says what it was built for: the argument block's size, voices per lane, sink and program must be THIS library's
+    uint32_t* dev = nullptr;
+    uint32_t got[4 + kMaxIns] = {0};
+    if (err == hipSuccess) err = hipMalloc(&dev, sizeof(got));
+    if (err == hipSuccess) {
+        void* params[] = {&dev};
+        err = hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, params, nullptr);
+        if (err == hipSuccess) err = hipMemcpy(got, dev, sizeof(got), hipMemcpyDeviceToHost);
+        (void)hipFree(dev);
+    }
+    if (err == hipSuccess &&
+        (got[0] != (uint32_t)sizeof(VpArgs) || got[1] != (uint32_t)e.vpt || got[2] != (uint32_t)e.C || got[3] != (uint32_t)e.n_ins ||
+         memcmp(got + 4, e.code, sizeof(uint32_t) * e.n_ins) != 0))
+        err = hipErrorInvalidImage;
+    if (err != hipSuccess) { (void)hipModuleUnload(e.mod); (void)hipGetLastError(); return (int)err; }
+    std::lock_guard<std::mutex> g(vp_specials_lock());
+    vp_specials().push_back(e);
+    return 0;
+}
+
+extern "C" int sig_voice_program_detach_all(void)
+{
+    std::lock_guard<std::mutex> g(vp_specials_lock());
+    for (VpSpecial& e : vp_specials()) (void)hipModuleUnload(e.mod);
+    vp_specials().clear();
+    return 0;
+}
+
 extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rate, int64_t position, int32_t block_frames,
                                  int32_t nblocks, int32_t context, int32_t voices, int32_t control_rows,
                                  int32_t hist_blocks, const int64_t* hist_positions, int32_t blocks_before,
@@ -726,8 +843,8 @@ extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rat
         }
         if (x.op == SIG_VP_AMP || x.op == SIG_VP_ADSR || x.op == SIG_VP_NOISE) need.ext = true;
         if (x.op == SIG_VP_ADSR) has_adsr = true;
-        a.code[k] = (uint32_t)x.op | ((uint32_t)x.kind << 5) | ((uint32_t)x.a << 8) | ((uint32_t)x.b << 12) | ((uint32_t)x.c << 16);
     }
+    SIG_CHECK_ARG(vp_encode(P, a.code));
     a.n_oscs = P.n_oscs; a.n_params = P.n_params; a.n_filters = P.n_filters;
     for (int k = 0; k < P.n_oscs; ++k) {
         SIG_CHECK_ARG(rows_ok(P.hertz[k], false) && rows_ok(P.phase[k], true));
@@ -773,7 +890,10 @@ extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rat
     if (bus_channels > 0 && sig_bus::tiles_sum_in_workgroup(a.voice_tiles)) { a.bus_out = out; a.bus_out_ld = out_ld; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     int err;
-    if (vpt == 2) err = small_file ? vp_launch_sink<2, true>(a, bus_channels, (unsigned)nwg, s)
+    if (hipFunction_t fn = vp_find_special(a, P, vpt, bus_channels)) {         // this very program, built as straight-line code
+        void* params[] = {&a};
+        err = (int)hipModuleLaunchKernel(fn, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr);
+    } else if (vpt == 2) err = small_file ? vp_launch_sink<2, true>(a, bus_channels, (unsigned)nwg, s)
                                    : vp_launch_sink<2, false>(a, bus_channels, (unsigned)nwg, s);
     else err = small_file ? vp_launch_sink<1, true>(a, bus_channels, (unsigned)nwg, s)
                           : vp_launch_sink<1, false>(a, bus_channels, (unsigned)nwg, s);
@@ -783,3 +903,4 @@ extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rat
         default: return sig_bus::launch_partials<2>(a.partials, a.voice_tiles, rows, out, out_ld, s);
     }
 }
+#endif  // SIG_VP_STATIC_CODE

@@ -182,7 +182,8 @@ class BatchRenderer:
     node (tails), the device status words of its filters, and the replay closure of a one-launch plan."""
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
-                 fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None):
+                 fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None,
+                 specialise: bool = False):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
@@ -190,6 +191,9 @@ class BatchRenderer:
         (sig_voice_program) instead of one kernel per node -- where the interpreter beats that schedule (programs that fit its
         small register file, and every block size below the filter context, which the per-node schedule cannot batch at all);
         'always': wherever the graph compiles.
+        `specialise`: build the voice-program kernel once more for exactly this graph's program (signals_amd/specialise.py:
+        hipcc, a few seconds at the first render, cached on disk) and launch that instead of the interpreter -- the same
+        arithmetic as straight-line code, 1.5-1.7x its rate; without hipcc the interpreter keeps running.
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -216,6 +220,7 @@ class BatchRenderer:
         # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program) -- True: where that beats
         # one kernel per node (_VoiceProgram.worthwhile), 'always': wherever the graph compiles
         self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)
+        self.specialise = bool(specialise)
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -1815,6 +1820,13 @@ class _VoiceProgram:
         seeds = tuple(self.seeds + [0, 0])[:2]
         if self.depth:
             o._virtual_history.add(self.top)
+        if o.specialise:
+            from . import specialise
+            C = out.shape[1] if bus else 0
+            aligned = v % 2 == 0 and out.stride(0) % 2 == 0 and out.data_ptr() % 8 == 0
+            vpl, _ = _native.voice_program_geometry(v, b.N, b.K, CONTEXT, self.depth, C, aligned)
+            if specialise.ensure(self.code, len(oscs), len(params), len(filters), self.n_temps, vpl, C):
+                label += '*specialised'
         return o._launch(label, lambda: _native.voice_program(self.code, oscs, params, filters, self.n_temps, self.depth, b.rate, b.pos,
                                                               b.N, b.K, CONTEXT, v, control_rows, hist, out, bus_gains=bus_gains, bus=bus,
                                                               adsr=adsr, noise_seeds=seeds, workspace=o._workspace if bus else None,
@@ -1845,6 +1857,12 @@ class _VoiceProgram:
         pull path, ~150 us per block)."""
         small_file = (len(self.filters) <= 2 and len(self.oscs) <= 3 and len(self.params) <= 4 and self.n_temps <= 1
                       and self.adsr is None and not self.seeds and not any(op == 'Amp' for op, *_ in self.code))
+        if self.batch.owner.specialise:
+            # a kernel built for this program has no interpreter to pay for: three filters in series 0.54 T against 0.26 per node,
+            # an Amp behind a filter level with it (f64 pow either way)
+            from . import specialise
+            if specialise.hipcc() is not None:
+                return True
         return small_file or (self.depth > 0 and self.batch.N < CONTEXT)
 
 

@@ -1,0 +1,107 @@
+"""Run-time specialisation of the voice-program kernel (signals_amd/csrc/voice_program.hip).
+
+The interpreter pays for its generality: the dispatch loop carries the whole register file through a `switch`, and the
+register allocator copies ~34 doubles per instruction word back into place.  The SAME source built with the
+program as a compile-time constant (`-DSIG_VP_STATIC_CODE={...}`) unrolls that loop and folds every switch: straight-line
+HIP for exactly one voice graph, 1.5-1.7x the interpreter's rate.  This module builds such an image with the ROCm compiler
+(`hipcc --genco`, ~3 s; cross-compiles without a GPU), caches it next to the package keyed by the kernel sources and the
+build's parameters, and attaches it to the library (`sig_voice_program_attach`), which from then on launches it whenever
+`sig_voice_program` is called with that program.  No hipcc, or a failed build: the interpreter keeps running (it is the
+same arithmetic; both are checked against the oracle by tests/test_gpu_specialise.py).
+
+Reference semantics are not touched: the image is voice_program.hip itself (same handlers, same block-sequence machine)."""
+import hashlib
+import os
+import pathlib
+import shutil
+import subprocess
+import threading
+
+from . import _native
+
+CSRC = pathlib.Path(__file__).resolve().parent / 'csrc'
+CACHE = pathlib.Path(os.environ.get('SIG_SPECIALISE_CACHE') or pathlib.Path(__file__).resolve().parent / '_specialised')
+SOURCES = ('voice_program.hip', 'sig_adsr.h', 'sig_biquad.h', 'sig_bus_tile.h', 'sig_osc.h', 'sig_common.h', '../../include/signals_amd.h')
+EXT_OPS = ('Amp', 'ADSR', 'Noise')
+
+_attached: set = set()
+_failed: set = set()
+_lock = threading.Lock()
+
+
+class SpecialiseError(RuntimeError):
+    pass
+
+
+def hipcc() -> str | None:
+    found = os.environ.get('HIPCC') or shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    return found if pathlib.Path(found).exists() else None
+
+
+def _source_digest() -> str:
+    h = hashlib.sha1()
+    for name in SOURCES:
+        h.update((CSRC / name).read_bytes())
+    return h.hexdigest()
+
+
+def flags(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> list:
+    """the macros that make voice_program.hip a kernel for exactly this program: the words, a register file of exactly the
+    slots it uses, voices per lane, sink, and the waves per SIMD the interpreter's small build asks for"""
+    words = ','.join(f'0x{w:x}' for w in _native.voice_program_words(code))
+    ext = int(any(op in EXT_OPS for op, *_ in code))
+    return [f'-DSIG_VP_STATIC_CODE={{{words}}}', f'-DSIG_VP_S_NF={max(n_filters, 1)}', f'-DSIG_VP_S_NO={max(n_oscs, 1)}',
+            f'-DSIG_VP_S_NP={max(n_params, 1)}', f'-DSIG_VP_S_NT={n_temps}', f'-DSIG_VP_S_EXT={ext}',
+            f'-DSIG_VP_STATIC_VPT={voices_per_lane}', f'-DSIG_VP_STATIC_C={bus_channels}',
+            f'-DSIG_VP_STATIC_WAVES={2 if voices_per_lane == 2 else 3}']
+
+
+def build(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bytes:
+    """the code object (gfx950) of voice_program.hip specialised for this program; cached on disk"""
+    defs = flags(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
+    key = hashlib.sha1((_source_digest() + ' '.join(defs)).encode()).hexdigest()[:24]
+    path = CACHE / f'vp_{key}.hsaco'
+    if path.exists():
+        return path.read_bytes()
+    cc = hipcc()
+    if cc is None:
+        raise SpecialiseError('hipcc not found (set HIPCC): voice programs stay on the interpreter')
+    CACHE.mkdir(parents=True, exist_ok=True)
+    tmp = path.with_suffix(f'.{os.getpid()}.{threading.get_ident()}.tmp')
+    cmd = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-Wno-unused-function', '--genco', *defs,
+           '-o', str(tmp), str(CSRC / 'voice_program.hip')]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    if done.returncode != 0 or not tmp.exists():
+        tmp.unlink(missing_ok=True)
+        raise SpecialiseError(f'hipcc failed on the specialised voice program:\n{done.stderr[-2000:]}')
+    os.replace(tmp, path)                                 # (atomic: another process may be building the same image)
+    return path.read_bytes()
+
+
+def ensure(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bool:
+    """build (or load from the cache) and attach the specialised kernel for this program once per process; False when that is
+    not possible here -- the caller's launches then run the interpreter"""
+    key = (tuple(code), n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
+    with _lock:
+        if key in _attached:
+            return True
+        if key in _failed:
+            return False
+        try:
+            image = build(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
+            _native.voice_program_attach(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels, image)
+        except (SpecialiseError, _native.NativeError) as e:
+            _failed.add(key)
+            import warnings
+            warnings.warn(f'voice program not specialised, the interpreter runs it: {e}')
+            return False
+        _attached.add(key)
+        return True
+
+
+def forget() -> None:
+    """detach every specialised kernel (tests)"""
+    with _lock:
+        _native.voice_program_detach_all()
+        _attached.clear()
+        _failed.clear()

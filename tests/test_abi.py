@@ -32,7 +32,7 @@ def test_header_and_binding_agree():
 def test_every_declared_symbol_is_exported(lib):
     for name in declared_symbols():
         assert getattr(lib, name) is not None, name
-    assert lib.sig_abi_version() == 6
+    assert lib.sig_abi_version() == 7
 
 
 def test_argument_errors_do_not_reach_the_device(lib):

@@ -1,0 +1,122 @@
+"""Specialised voice-program kernels (signals_amd/specialise.py, sig_voice_program_attach): voice_program.hip built for ONE
+program must give what the interpreter gives -- the same source, the same arithmetic -- and both what the oracle gives."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RATE, f32, maxerr
+import test_gpu_program_engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _device(tmp_path_factory):
+    assert torch.cuda.is_available()
+    from signals_amd import _native, runtime, specialise
+    runtime.set_device('cuda:0')
+    if specialise.hipcc() is None:
+        pytest.skip('no hipcc on this machine: nothing to specialise with')
+    yield
+    torch.cuda.synchronize()
+    specialise.forget()
+    _native.voice_program_use_attached(True)
+    _native.set_voice_program_tuning()
+
+
+def names(timer):
+    torch.cuda.synchronize()
+    return set(timer.summary())
+
+
+@pytest.mark.parametrize('which', E.SHAPES)
+def test_specialised_kernel_equals_the_interpreter_and_the_oracle(which):
+    """the shapes of tests/test_gpu_program_engine.py (Amp / RingMod / Mix behind filters, three filters in series, FM with a
+    second oscillator, a swept cascade with a tremolo: fx.py:35-60, :85-121, osc.py:26-62), stored and under a stereo bus,
+    continuing batches, two launch geometries"""
+    from oracle import chain_ref as R
+    from signals_amd import _native
+    from signals_amd.chain import ext
+    from signals_amd.engine import KernelTimer
+    V, N, batches = 96, 256, (3, 1, 4)
+    p = E.draw(V, 13)
+    p['cut1'][0, :8] = np.linspace(25.0, 140.0, 8)
+    node, ref_node = E.shapes(p, which)
+    ref = R.render_stream(ref_node, 0, N, sum(batches), V)
+    scale = max(1.0, np.nanmax(np.abs(ref)))
+    for vpl in (1, 2):
+        _native.set_voice_program_tuning(vpl, 2)
+        node, _ = E.shapes(p, which)
+        plain = E.render_batches(node, V, 0, N, batches, fuse_program='always')
+        node, _ = E.shapes(p, which)
+        timer = KernelTimer()
+        got = E.render_batches(node, V, 0, N, batches, timer, fuse_program='always', specialise=True)
+        assert any(n.startswith('voice_program[') and n.endswith('*specialised') for n in names(timer)), names(timer)
+        assert maxerr(got, f32(ref)) < 1e-6 * scale, (which, vpl)
+        assert maxerr(got, plain) <= 2.5e-7 * scale, (which, vpl)             # (the same operations; the compiler may order a sum differently)
+        # under a bus
+        node, _ = E.shapes(p, which)
+        bus = ext.SumBus(); bus.input = node; bus.get_state().gains = np.ascontiguousarray(p['pan'])
+        plain = E.render_batches(bus, 2, 0, N, batches, fuse_program='always')
+        node, _ = E.shapes(p, which)
+        bus = ext.SumBus(); bus.input = node; bus.get_state().gains = np.ascontiguousarray(p['pan'])
+        timer = KernelTimer()
+        got = E.render_batches(bus, 2, 0, N, batches, timer, fuse_program='always', specialise=True)
+        assert any(n.startswith('voice_program_bus[') and n.endswith('*specialised') for n in names(timer)), names(timer)
+        if which != 'amp_after_filter':
+            want = ref @ p['pan'].T
+            assert maxerr(got, f32(want)) < 1e-6 * max(1.0, np.abs(want).max()), (which, vpl)
+        ok = np.isfinite(plain) & np.isfinite(got)
+        assert np.array_equal(np.isfinite(plain), np.isfinite(got))
+        if ok.any():                                                          # (Amp's NaN voices poison every row of a bus)
+            assert np.abs(got[ok].astype(np.float64) - plain[ok]).max() <= 2.5e-7 * max(1.0, np.abs(plain[ok]).max()), (which, vpl)
+    _native.set_voice_program_tuning()
+
+
+@pytest.mark.parametrize('N', [32, 64, 100])
+def test_specialised_kernel_on_blocks_no_longer_than_the_context(N):
+    """the four-step form for blocks shorter than the filter context (chain/__init__.py:266-303) is part of the same source"""
+    from oracle import chain_ref as R
+    from signals_amd.engine import KernelTimer
+    V = 64
+    p = E.draw(V, 17)
+    p['cut1'][0, :6] = np.linspace(30.0, 150.0, 6)
+    batches = (3, 2, 4)
+    node, ref_node = E.shapes(p, 'modulated_cascade')
+    ref = R.render_stream(ref_node, 0, N, sum(batches), V)
+    timer = KernelTimer()
+    got = E.render_batches(node, V, 0, N, batches, timer, fuse_program='always', specialise=True)
+    assert any(n.endswith('*specialised') for n in names(timer)), names(timer)
+    assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), N
+
+
+def test_switching_attached_kernels_off_and_refusing_a_foreign_image():
+    from signals_amd import _native, specialise
+    code_a = [('Osc', 2, 0, 0, 0), ('Gain', 0, 0, 0, 0)]
+    code_b = [('Osc', 3, 0, 0, 0), ('Gain', 0, 0, 0, 0)]
+    image_a = specialise.build(code_a, 1, 1, 0, 0, 1, 0)
+    with pytest.raises(_native.NativeError):                                  # built for another program: hipErrorInvalidImage
+        _native.voice_program_attach(code_b, 1, 1, 0, 0, 1, 0, image_a)
+    with pytest.raises(_native.NativeError):                                  # ... another geometry
+        _native.voice_program_attach(code_a, 1, 1, 0, 0, 2, 0, image_a)
+    with pytest.raises(_native.NativeError):                                  # not a code object at all
+        _native.voice_program_attach(code_a, 1, 1, 0, 0, 1, 0, b'\x7fELF' + bytes(4096))
+    assert specialise.ensure(code_a, 1, 1, 0, 0, 1, 0)
+    V, N, K = 64, 256, 3
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device='cuda')
+    rng = np.random.default_rng(3)
+    hz, ph, g = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V)), rng.uniform(0.1, 1, (1, V))
+    _native.set_voice_program_tuning(1, 1)
+
+    def run():
+        out = torch.full((N * K, V), float('nan'), device='cuda')
+        _native.voice_program(code_a, [(dev(hz), dev(ph))], [dev(g)], [], 0, 0, RATE, 4800, N, K, 100, V, 1 + K, [], out)
+        return out.cpu().numpy()
+    special = run()
+    _native.voice_program_use_attached(False)
+    interpreted = run()
+    _native.voice_program_use_attached(True)
+    from oracle import chain_ref as R
+    ref = R.gain(R.osc('Sawtooth', 4800, N * K, RATE, hz, ph), g)
+    assert np.array_equal(special, interpreted)                               # Sawtooth and a product: the same bits either way
+    assert np.array_equal(special, f32(ref))

@@ -83,10 +83,12 @@ def shapes(V):
                                     two_filters_tremolo, osc_gain_only)}
 
 
-def rate(build, V, N, K, program, steps=10):
+def rate(build, V, N, K, program, steps=10, specialise=False):
+    from signals_amd import _native
     from signals_amd.engine import BatchRenderer, KernelTimer
+    _native.voice_program_use_attached(bool(specialise))    # (attached kernels are process-wide: an interpreter run must not pick one up)
     timer = KernelTimer(sample_every=4)
-    r = BatchRenderer(build(), 2, RATE, timer=timer, fuse_program=program)
+    r = BatchRenderer(build(), 2, RATE, timer=timer, fuse_program=program, specialise=specialise)
     pos = 0
     t_end = time.perf_counter() + 0.3
     while time.perf_counter() < t_end:
@@ -109,6 +111,8 @@ if __name__ == '__main__':
     V = 1024
     for name, build in shapes(V).items():
         fast, launches = rate(build, V, N, K, True)
+        spec, spec_launches = rate(build, V, N, K, 'always', specialise=True)
         slow, per_node = rate(build, V, N, K, False, steps=4)
         print(json.dumps({'shape': name, 'voices': V, 'block_frames': N, 'blocks_per_batch': K, 'T_voice_samples_per_s': round(fast, 3),
-                          'launches_us': launches, 'per_node_T': round(slow, 3), 'per_node_launches_us': per_node}), flush=True)
+                          'launches_us': launches, 'specialised_T': round(spec, 3), 'specialised_launches_us': spec_launches,
+                          'per_node_T': round(slow, 3), 'per_node_launches_us': per_node}), flush=True)
