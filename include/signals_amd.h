@@ -489,10 +489,14 @@ int sig_voice_program(const sig_voice_program_t* program, int32_t rate, int64_t 
 /* Tuning / test hook: force the voices per lane (1, 2; 0 = heuristic; ignored where the program does not fit the variant) and
  * the blocks per lane (0 = heuristic) of sig_voice_program.  Process-wide. */
 int sig_voice_program_set_tuning(int32_t voices_per_lane, int32_t blocks_per_lane);
-/* Introspection, no device work: the voices per lane (1 | 2) and blocks per lane sig_voice_program picks for a problem;
- * store_aligned: bus_channels == 0 and `out` is 8-byte aligned with even voices and out_ld. */
+/* Introspection, no device work: the voices per lane and blocks per lane sig_voice_program picks for a problem.
+ * store_aligned (bus_channels == 0): 4 = `out` 16-byte aligned with voices and out_ld multiples of 4, 2 = 8-byte aligned with
+ * even voices and out_ld, else 1.  specialised != 0: as if a kernel specialised for four voices per lane were attached (the
+ * interpreter runs one or two; sig_voice_program takes four where such an image is attached, the store is aligned for it or
+ * there is a bus, and the launch still has a wave for every SIMD) -- what to build the image for. */
 int sig_voice_program_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context, int32_t depth,
-                               int32_t bus_channels, int32_t store_aligned, int32_t* voices_per_lane, int32_t* blocks_per_lane);
+                               int32_t bus_channels, int32_t store_aligned, int32_t specialised,
+                               int32_t* voices_per_lane, int32_t* blocks_per_lane);
 /* SPECIALISED kernels.  The interpreter's source (signals_amd/csrc/voice_program.hip) built once more as a gfx950 code object
  * with ONE program as a compile-time constant -- macros SIG_VP_STATIC_CODE={words}, SIG_VP_S_NF / _NO / _NP / _NT / _EXT (the
  * register file: filter, oscillator, parameter, temporary slots; Amp / ADSR / White enabled), SIG_VP_STATIC_VPT, SIG_VP_STATIC_C,

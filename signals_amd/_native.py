@@ -190,7 +190,7 @@ def lib() -> ctypes.CDLL:
         L.sig_voice_program_set_tuning.restype = ctypes.c_int
         L.sig_voice_program_set_tuning.argtypes = [i32, i32]
         L.sig_voice_program_geometry.restype = ctypes.c_int
-        L.sig_voice_program_geometry.argtypes = [i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.sig_voice_program_geometry.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         L.sig_voice_program_args_size.restype = ctypes.c_int64
         L.sig_voice_program_args_size.argtypes = []
         L.sig_voice_program_attach.restype = ctypes.c_int
@@ -1082,11 +1082,12 @@ def voice_program_words(code: list) -> list:
 
 
 def voice_program_geometry(voices: int, block_frames: int, nblocks: int, context: int, depth: int, bus_channels: int,
-                           store_aligned: bool) -> tuple:
-    """(voices per lane, blocks per lane) sig_voice_program picks for this problem (introspection, no device work)"""
+                           store_aligned: int, specialised: bool = False) -> tuple:
+    """(voices per lane, blocks per lane) sig_voice_program picks for this problem (introspection, no device work);
+    store_aligned: 4 | 2 | 1 (see the header); specialised: with a kernel built for four voices per lane at hand"""
     vpt, span = ctypes.c_int32(0), ctypes.c_int32(0)
-    _check(lib().sig_voice_program_geometry(voices, block_frames, nblocks, context, depth, bus_channels, 1 if store_aligned else 0,
-                                            ctypes.byref(vpt), ctypes.byref(span)), 'sig_voice_program_geometry')
+    _check(lib().sig_voice_program_geometry(voices, block_frames, nblocks, context, depth, bus_channels, int(store_aligned),
+                                            1 if specialised else 0, ctypes.byref(vpt), ctypes.byref(span)), 'sig_voice_program_geometry')
     return vpt.value, span.value
 
 

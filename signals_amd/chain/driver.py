@@ -54,6 +54,7 @@ class BlockDriver(Receiver):
         self._engine = None
         self._engine_key = None
         self._engine_ok = True
+        self.engine_options: dict = {}                        # further BatchRenderer keywords (`fuse_program`, `specialise` ...)
 
     @classmethod
     def flags(cls) -> SignalFlags:
@@ -96,7 +97,8 @@ class BlockDriver(Receiver):
         key = (chain.graph_clock.version, self.input.sig, self._state.channels, self.rate)
         if self._engine_key != key:
             # pull() copies every block to the host before asking for the next: graph-owned buffers are safe
-            self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate, graph_replay=True)
+            self._engine = engine.BatchRenderer(self.input.sig, self._state.channels, self.rate, graph_replay=True,
+                                                **self.engine_options)
             self._engine_key = key
             self._engine_ok = True
         if not self._engine_ok:

@@ -129,8 +129,10 @@ __device__ __noinline__ double vp_amp(double x, double e) { return copysign(pow(
 template <int VPT> struct VpOut;
 template <> struct VpOut<1> { using type = float; };
 template <> struct VpOut<2> { using type = float2; };
+template <> struct VpOut<4> { using type = float4; };
 __device__ __forceinline__ void vp_put(float& v, const float (&y)[1]) { v = y[0]; }
 __device__ __forceinline__ void vp_put(float2& v, const float (&y)[2]) { v = make_float2(y[0], y[1]); }
+__device__ __forceinline__ void vp_put(float4& v, const float (&y)[4]) { v = make_float4(y[0], y[1], y[2], y[3]); }
 
 // Register-file sizes per variant (the host picks the smallest variant a program fits).  SMALL: two filter slots, three
 // oscillator slots, four parameter registers, one temporary (a temporary is a whole row group: 8 rows x 2 voices = 32 VGPRs), no Amp / ADSR / White -- the common synthesiser voice; its
@@ -703,16 +705,21 @@ bool fits_small(const VpNeeds& n) {
 // voices per lane and blocks per lane.  4 voices per lane amortise the interpreter's scalar work best; a lane's span
 // re-walks (depth - 1) blocks + the context once, so longer spans waste less -- while the launch still has a wave or two
 // for every SIMD
-void vp_geometry(const VpArgs& a, bool store_aligned2, int& vpt, int& span) {
+// `four`: a kernel SPECIALISED for four voices per lane is at hand (the interpreter exists for 1 and 2): straight-line code
+// keeps a lone wave per SIMD busy, and the bus flush and the row's n / rate are paid per lane -- taken when the store is
+// 16-byte aligned (or there is a bus) and the launch still has a wave for every SIMD
+void vp_geometry(const VpArgs& a, int store_aligned, bool four, int& vpt, int& span) {
     auto waves = [&](int v, int s) { return (int64_t)((a.voices + SIG_WAVE * v - 1) / (SIG_WAVE * v)) * ((a.K + s - 1) / s); };
     const bool bus = a.partials != nullptr;
-    vpt = ((bus || store_aligned2) && waves(2, 1) >= 1024) ? 2 : 1;
+    vpt = ((bus || store_aligned >= 2) && waves(2, 1) >= 1024) ? 2 : 1;
+    const bool can4 = four && (bus || store_aligned >= 4);
+    if (can4 && waves(4, 1) >= 1024) vpt = 4;
     const int t = vp_tuning().vpt;
-    if (t == 1 || (t == 2 && (bus || store_aligned2))) vpt = t;
+    if (t == 1 || (t == 2 && (bus || store_aligned >= 2)) || (t == 4 && can4)) vpt = t;
     span = 1;
     if (!a.small) {
         span = 16;
-        while (span > 1 && waves(vpt, span) < 2048) span >>= 1;
+        while (span > 1 && waves(vpt, span) < (vpt == 4 ? 1024 : 2048)) span >>= 1;
         if (vp_tuning().span >= 1) span = vp_tuning().span;
     }
 }
@@ -739,7 +746,8 @@ extern "C" int sig_voice_program_set_tuning(int32_t voices_per_lane, int32_t blo
 }
 
 extern "C" int sig_voice_program_geometry(int32_t voices, int32_t block_frames, int32_t nblocks, int32_t context, int32_t depth,
-                                          int32_t bus_channels, int32_t store_aligned, int32_t* voices_per_lane, int32_t* blocks_per_lane)
+                                          int32_t bus_channels, int32_t store_aligned, int32_t specialised,
+                                          int32_t* voices_per_lane, int32_t* blocks_per_lane)
 {
     SIG_CHECK_ARG(voices >= 0 && block_frames >= 0 && nblocks >= 0 && context >= 0 && depth >= 0 && voices_per_lane && blocks_per_lane);
     VpArgs a{};
@@ -748,7 +756,7 @@ extern "C" int sig_voice_program_geometry(int32_t voices, int32_t block_frames, 
     double dummy = 0.0;
     a.partials = bus_channels > 0 ? &dummy : nullptr;                          // (only asked whether there is a bus)
     int vpt = 1, span = 1;
-    vp_geometry(a, store_aligned != 0, vpt, span);
+    vp_geometry(a, store_aligned, specialised != 0, vpt, span);
     *voices_per_lane = vpt; *blocks_per_lane = span;
     return 0;
 }
@@ -760,7 +768,7 @@ extern "C" int sig_voice_program_use_attached(int32_t on) { vp_tuning().attached
 extern "C" int sig_voice_program_attach(const sig_voice_program_t* program, int32_t voices_per_lane, int32_t bus_channels,
                                         const void* image)
 {
-    SIG_CHECK_ARG(program && image && (voices_per_lane == 1 || voices_per_lane == 2) && bus_channels >= 0 && bus_channels <= 2);
+    SIG_CHECK_ARG(program && image && (voices_per_lane == 1 || voices_per_lane == 2 || voices_per_lane == 4) && bus_channels >= 0 && bus_channels <= 2);
     const sig_voice_program_t& P = *program;
     SIG_CHECK_ARG(P.n_ins >= 1 && P.n_ins <= SIG_VP_MAX_INS);
     VpSpecial e{};
@@ -880,9 +888,10 @@ extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rat
     } else {
         a.out = out; a.out_ld = out_ld;
     }
-    const bool al2 = voices % 2 == 0 && out_ld % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    const int aligned = (voices % 4 == 0 && out_ld % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 4
+                      : (voices % 2 == 0 && out_ld % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0) ? 2 : 1;
     int vpt = 1;
-    vp_geometry(a, al2, vpt, a.span);
+    vp_geometry(a, aligned, vp_find_special(a, P, 4, bus_channels) != nullptr, vpt, a.span);
     const bool small_file = fits_small(need);
     a.voice_tiles = (voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
     const int64_t nwg = ((int64_t)a.voice_tiles * ((a.K + a.span - 1) / a.span) + 3) / 4;
@@ -893,6 +902,8 @@ extern "C" int sig_voice_program(const sig_voice_program_t* program, int32_t rat
     if (hipFunction_t fn = vp_find_special(a, P, vpt, bus_channels)) {         // this very program, built as straight-line code
         void* params[] = {&a};
         err = (int)hipModuleLaunchKernel(fn, (unsigned)nwg, 1, 1, 256, 1, 1, 0, s, params, nullptr);
+    } else if (vpt == 4) {
+        return (int)hipErrorInvalidValue;                                      // (forced by the tuning hook after the image was switched off)
     } else if (vpt == 2) err = small_file ? vp_launch_sink<2, true>(a, bus_channels, (unsigned)nwg, s)
                                    : vp_launch_sink<2, false>(a, bus_channels, (unsigned)nwg, s);
     else err = small_file ? vp_launch_sink<1, true>(a, bus_channels, (unsigned)nwg, s)

@@ -1823,10 +1823,16 @@ class _VoiceProgram:
         if o.specialise:
             from . import specialise
             C = out.shape[1] if bus else 0
-            aligned = v % 2 == 0 and out.stride(0) % 2 == 0 and out.data_ptr() % 8 == 0
-            vpl, _ = _native.voice_program_geometry(v, b.N, b.K, CONTEXT, self.depth, C, aligned)
-            if specialise.ensure(self.code, len(oscs), len(params), len(filters), self.n_temps, vpl, C):
-                label += '*specialised'
+            aligned = (4 if v % 4 == 0 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0 else
+                       2 if v % 2 == 0 and out.stride(0) % 2 == 0 and out.data_ptr() % 8 == 0 else 1)
+            # four voices per lane (one wave per SIMD) pay for programs without filter state or temporaries -- an oscillator bank
+            # under a bus: 176 -> 144 us per 268 M voice-samples; with two filters 356 -> 396 us, with a temporary 380 -> 899 us.
+            # The launch takes four only with such an image attached, so the choice is made here
+            for four in ((True, False) if not filters and self.n_temps == 0 else (False,)):
+                vpl, _ = _native.voice_program_geometry(v, b.N, b.K, CONTEXT, self.depth, C, aligned, specialised=four)
+                if specialise.ensure(self.code, len(oscs), len(params), len(filters), self.n_temps, vpl, C):
+                    label += '*specialised'
+                    break
         return o._launch(label, lambda: _native.voice_program(self.code, oscs, params, filters, self.n_temps, self.depth, b.rate, b.pos,
                                                               b.N, b.K, CONTEXT, v, control_rows, hist, out, bus_gains=bus_gains, bus=bus,
                                                               adsr=adsr, noise_seeds=seeds, workspace=o._workspace if bus else None,

@@ -70,12 +70,13 @@ class ShardedRenderer:
     [lo, hi); per-voice parameter rows are sliced once, at graph-build time."""
 
     def __init__(self, build: typing.Callable[[int, int], 'object'], total_voices: int, bus_channels: int,
-                 rate: int = 48000, group: int = 1, timer=None, fuse: bool = True):
+                 rate: int = 48000, group: int = 1, timer=None, fuse: bool = True, **engine_options):
+        """`engine_options`: further BatchRenderer keywords (`fuse_program`, `specialise` ...), the same on every rank"""
         from signals_amd.engine import BatchRenderer
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.lo, self.hi = shard_voices(total_voices, self.world, self.rank, group)
-        self.renderer = BatchRenderer(build(self.lo, self.hi), bus_channels, rate, timer=timer, fuse=fuse)
+        self.renderer = BatchRenderer(build(self.lo, self.hi), bus_channels, rate, timer=timer, fuse=fuse, **engine_options)
 
     def render(self, position: int, block_frames: int, nblocks: int, dst: typing.Optional[int] = None) -> torch.Tensor:
         """the mixed bus on every rank (dst None: all-reduce) or on rank `dst` only (reduce: half the traffic)"""

@@ -53,7 +53,7 @@ def flags(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, 
     return [f'-DSIG_VP_STATIC_CODE={{{words}}}', f'-DSIG_VP_S_NF={max(n_filters, 1)}', f'-DSIG_VP_S_NO={max(n_oscs, 1)}',
             f'-DSIG_VP_S_NP={max(n_params, 1)}', f'-DSIG_VP_S_NT={n_temps}', f'-DSIG_VP_S_EXT={ext}',
             f'-DSIG_VP_STATIC_VPT={voices_per_lane}', f'-DSIG_VP_STATIC_C={bus_channels}',
-            f'-DSIG_VP_STATIC_WAVES={2 if voices_per_lane == 2 else 3}']
+            f'-DSIG_VP_STATIC_WAVES={ {1: 3, 2: 2, 4: 1}[voices_per_lane] }']
 
 
 def build(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bytes:
