@@ -38,6 +38,7 @@ cascaded filters with N <= 100) raise `NotBatchable`; callers fall back to the e
 """
 from __future__ import annotations
 
+import os
 import typing
 
 import torch
@@ -183,7 +184,7 @@ class BatchRenderer:
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
                  fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None,
-                 specialise: bool = False):
+                 specialise: bool | None = None):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
@@ -193,7 +194,8 @@ class BatchRenderer:
         'always': wherever the graph compiles.
         `specialise`: build the voice-program kernel once more for exactly this graph's program (signals_amd/specialise.py:
         hipcc, a few seconds at the first render, cached on disk) and launch that instead of the interpreter -- the same
-        arithmetic as straight-line code, 1.5-1.7x its rate; without hipcc the interpreter keeps running.
+        arithmetic as straight-line code, 1.6-2x its rate; without hipcc the interpreter keeps running.  Default: off, or the
+        environment's SIG_SPECIALISE=1.
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -220,7 +222,7 @@ class BatchRenderer:
         # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program) -- True: where that beats
         # one kernel per node (_VoiceProgram.worthwhile), 'always': wherever the graph compiles
         self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)
-        self.specialise = bool(specialise)
+        self.specialise = bool(int(os.environ.get('SIG_SPECIALISE', '0'))) if specialise is None else bool(specialise)
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
