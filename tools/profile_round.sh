@@ -9,7 +9,9 @@ out=$root/gpurun_out/prof$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $root/bench.py --no-cpu-baseline --single-mode"
-for mode in fused materialised; do
+modes="fused materialised"
+[ "${2:-}" = configs ] && modes=""          # tools/profile_round.sh <tag> configs: only the passes over tools/measure_configs.py
+for mode in $modes; do
   flag=""; [ $mode = materialised ] && flag="--materialised"
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$mode -- $BENCH --steps 20 --warmup 5 $flag \
       > $out/stats_$mode.json 2> $out/stats_$mode.err
@@ -20,6 +22,7 @@ for mode in fused materialised; do
     echo "pmc $mode $ctr done"
   done
 done
+if [ -n "$modes" ]; then
 # issue-side counters of the headline (fused) schedule: 8 SQ slots + GRBM per pass
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $out/pmc_fused_SQ_issue -- $BENCH --steps 6 --warmup 2 --prewarm-ms 100 --no-kernel-timing > $out/pmc_fused_SQ_issue.log 2>&1
@@ -29,6 +32,7 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CON
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_k256 -- $BENCH --steps 200 --warmup 20 --blocks 256 \
     > $out/stats_k256.json 2> $out/stats_k256.err
 echo "SQ passes done"
+fi
 # BASELINE configs 3 and 5 (tools/measure_configs.py renders both through the engine's default schedule)
 CFG="python3 $root/tools/measure_configs.py 6"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_configs -- $CFG > $out/stats_configs.json 2> $out/stats_configs.err
