@@ -66,16 +66,19 @@ def build(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, 
     cc = hipcc()
     if cc is None:
         raise SpecialiseError('hipcc not found (set HIPCC): voice programs stay on the interpreter')
-    CACHE.mkdir(parents=True, exist_ok=True)
-    tmp = path.with_suffix(f'.{os.getpid()}.{threading.get_ident()}.tmp')
-    cmd = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-Wno-unused-function', '--genco', *defs,
-           '-o', str(tmp), str(CSRC / 'voice_program.hip')]
-    done = subprocess.run(cmd, capture_output=True, text=True)
-    if done.returncode != 0 or not tmp.exists():
-        tmp.unlink(missing_ok=True)
-        raise SpecialiseError(f'hipcc failed on the specialised voice program:\n{done.stderr[-2000:]}')
-    os.replace(tmp, path)                                 # (atomic: another process may be building the same image)
-    return path.read_bytes()
+    try:
+        CACHE.mkdir(parents=True, exist_ok=True)
+        tmp = path.with_suffix(f'.{os.getpid()}.{threading.get_ident()}.tmp')
+        cmd = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-Wno-unused-function', '--genco', *defs,
+               '-o', str(tmp), str(CSRC / 'voice_program.hip')]
+        done = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if done.returncode != 0 or not tmp.exists():
+            tmp.unlink(missing_ok=True)
+            raise SpecialiseError(f'hipcc failed on the specialised voice program:\n{done.stderr[-2000:]}')
+        os.replace(tmp, path)                             # (atomic: another process may be building the same image)
+        return path.read_bytes()
+    except (OSError, subprocess.TimeoutExpired) as e:     # a read-only package directory, a compiler that cannot be started ...
+        raise SpecialiseError(f'specialised voice program not built: {e}') from e
 
 
 def ensure(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bool:
