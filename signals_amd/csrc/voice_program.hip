@@ -384,6 +384,13 @@ __device__ __forceinline__ void vp_wave(const VpArgs& a, double* tile, int lane,
 #ifdef SIG_VP_STATIC_CODE
         // a specialised build: the program is a compile-time constant, the loop is unrolled and every switch below folds away
         constexpr uint32_t kStatic[] = SIG_VP_STATIC_CODE;
+        constexpr bool kStaticExt = [] {
+            constexpr uint32_t c[] = SIG_VP_STATIC_CODE;
+            bool ext = false;
+            for (unsigned k = 0; k < sizeof(c) / sizeof(c[0]); ++k) ext |= (c[k] & 31u) >= (uint32_t)SIG_VP_AMP;
+            return ext;
+        }();
+        static_assert(EXT || !kStaticExt, "the program uses Amp / ADSR / White: build with -DSIG_VP_S_EXT=1");
 #pragma unroll
         for (int pc = 0; pc < (int)(sizeof(kStatic) / sizeof(kStatic[0])); ++pc) {
             const uint32_t w = kStatic[pc];

@@ -22,7 +22,6 @@ from . import _native
 CSRC = pathlib.Path(__file__).resolve().parent / 'csrc'
 CACHE = pathlib.Path(os.environ.get('SIG_SPECIALISE_CACHE') or pathlib.Path(__file__).resolve().parent / '_specialised')
 SOURCES = ('voice_program.hip', 'sig_adsr.h', 'sig_biquad.h', 'sig_bus_tile.h', 'sig_osc.h', 'sig_common.h', '../../include/signals_amd.h')
-EXT_OPS = ('Amp', 'ADSR', 'Noise')
 
 _attached: set = set()
 _failed: set = set()
@@ -49,7 +48,7 @@ def flags(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, 
     """the macros that make voice_program.hip a kernel for exactly this program: the words, a register file of exactly the
     slots it uses, voices per lane, sink, and the waves per SIMD the interpreter's small build asks for"""
     words = ','.join(f'0x{w:x}' for w in _native.voice_program_words(code))
-    ext = int(any(op in EXT_OPS for op, *_ in code))
+    ext = int(any(_native.VP_OPS[op] >= _native.VP_OPS['Amp'] for op, *_ in code))        # Amp, Adsr, Noise: the extended handlers
     return [f'-DSIG_VP_STATIC_CODE={{{words}}}', f'-DSIG_VP_S_NF={max(n_filters, 1)}', f'-DSIG_VP_S_NO={max(n_oscs, 1)}',
             f'-DSIG_VP_S_NP={max(n_params, 1)}', f'-DSIG_VP_S_NT={n_temps}', f'-DSIG_VP_S_EXT={ext}',
             f'-DSIG_VP_STATIC_VPT={voices_per_lane}', f'-DSIG_VP_STATIC_C={bus_channels}',

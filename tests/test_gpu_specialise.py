@@ -47,7 +47,9 @@ def test_specialised_kernel_equals_the_interpreter_and_the_oracle(which):
     for vpl in (1, 2):
         _native.set_voice_program_tuning(vpl, 2)
         node, _ = E.shapes(p, which)
+        _native.voice_program_use_attached(False)                             # (attached kernels are process-wide)
         plain = E.render_batches(node, V, 0, N, batches, fuse_program='always')
+        _native.voice_program_use_attached(True)
         node, _ = E.shapes(p, which)
         timer = KernelTimer()
         got = E.render_batches(node, V, 0, N, batches, timer, fuse_program='always', specialise=True)
@@ -57,7 +59,9 @@ def test_specialised_kernel_equals_the_interpreter_and_the_oracle(which):
         # under a bus
         node, _ = E.shapes(p, which)
         bus = ext.SumBus(); bus.input = node; bus.get_state().gains = np.ascontiguousarray(p['pan'])
+        _native.voice_program_use_attached(False)
         plain = E.render_batches(bus, 2, 0, N, batches, fuse_program='always')
+        _native.voice_program_use_attached(True)
         node, _ = E.shapes(p, which)
         bus = ext.SumBus(); bus.input = node; bus.get_state().gains = np.ascontiguousarray(p['pan'])
         timer = KernelTimer()
@@ -88,6 +92,55 @@ def test_specialised_kernel_on_blocks_no_longer_than_the_context(N):
     got = E.render_batches(node, V, 0, N, batches, timer, fuse_program='always', specialise=True)
     assert any(n.endswith('*specialised') for n in names(timer)), names(timer)
     assert maxerr(got, f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max()), N
+
+
+@pytest.mark.parametrize('which', ['envelope_left', 'envelope_right', 'noise_gate'])
+def test_specialised_kernel_with_the_extended_handlers(which):
+    """programs with an ADSR or White instruction need the extended handlers compiled in (SIG_VP_S_EXT): RingMod of an envelope
+    and a filtered oscillator, either way round, against the eager pull path from position 0 and on a fresh graph mid-stream;
+    White (noise.py:22-23, unseeded in the reference: statistics only) against the interpreter"""
+    from helpers import fix, mkosc, stream
+    from signals_amd import _native
+    from signals_amd.chain import ext, fx, noise
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V = 8
+    rng = np.random.default_rng(5)
+    row = lambda lo, hi, wide=True: rng.uniform(lo, hi, (1, V if wide else 1))
+    P = dict(hz=row(55, 1760), cut=row(300, 6000), attack=row(0.001, 0.008), decay=row(0.002, 0.008), sustain=row(0.2, 0.9),
+             release=row(0.002, 0.01), gate_on=row(0.0, 0.006), gate_off=row(0.012, 0.03, wide=False), g=row(0.2, 1.0))
+
+    def build():
+        o = mkosc('Sawtooth', P['hz'])
+        f = fx.HighPass(); f.input = o; f.cutoff = fix(P['cut'])
+        if which == 'noise_gate':
+            w = noise.White(); w.get_state().channels = V
+            m = fx.RingMod(); m.left = f; m.right = w
+            g = fx.Gain(); g.left = m; g.right = fix(P['g'])
+            return g
+        env = ext.ADSR()
+        for name in ('attack', 'decay', 'sustain', 'release', 'gate_on', 'gate_off'):
+            setattr(env, name, fix(P[name]))
+        n = fx.RingMod()
+        n.left, n.right = (env, f) if which == 'envelope_left' else (f, env)
+        return n
+    for pos, N, K in ((0, 128, 3), (1000, 256, 2), (0, 64, 4)):
+        for vpl in (1, 2):
+            _native.set_voice_program_tuning(vpl, 1)
+            _native.voice_program_use_attached(False)
+            plain = BatchRenderer(build(), V, RATE, fuse_program='always').render(pos, N, K).cpu().numpy()
+            _native.voice_program_use_attached(True)
+            timer = KernelTimer()
+            got = BatchRenderer(build(), V, RATE, fuse_program='always', specialise=True, timer=timer).render(pos, N, K).cpu().numpy()
+            assert any(n.endswith('*specialised') for n in names(timer)), names(timer)
+            if which == 'noise_gate':
+                per_node = BatchRenderer(build(), V, RATE, fuse_program=False).render(pos, N, K).cpu().numpy()
+                assert maxerr(got, plain) < 1e-6 and maxerr(got, per_node) < 1e-6     # one counter-based generator (noise.hip) everywhere: the same samples
+                assert np.abs(got).max() > 1e-3
+            else:
+                want = stream(build(), pos, N, K, V)
+                assert maxerr(plain, want) < 1e-6, (which, pos, N, vpl)
+                assert maxerr(got, want) < 1e-6, (which, pos, N, vpl)
+    _native.set_voice_program_tuning()
 
 
 def test_switching_attached_kernels_off_and_refusing_a_foreign_image():
