@@ -184,7 +184,7 @@ class BatchRenderer:
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
                  fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None,
-                 specialise: bool | None = None):
+                 specialise: bool | str | None = None):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
@@ -194,8 +194,9 @@ class BatchRenderer:
         'always': wherever the graph compiles.
         `specialise`: build the voice-program kernel once more for exactly this graph's program (signals_amd/specialise.py:
         hipcc, a few seconds at the first render, cached on disk) and launch that instead of the interpreter -- the same
-        arithmetic as straight-line code, 1.6-2x its rate; without hipcc the interpreter keeps running.  Default: off, or the
-        environment's SIG_SPECIALISE=1.
+        arithmetic as straight-line code, 1.6-2x its rate; without hipcc the interpreter keeps running.  'background': the build
+        runs on a worker thread and the interpreter renders until the kernel is attached (a real-time sink never waits for
+        the compiler).  Default: off, or the environment's SIG_SPECIALISE=1.
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -222,7 +223,7 @@ class BatchRenderer:
         # graphs no fused kernel covers: the per-voice graph as ONE interpreted launch (sig_voice_program) -- True: where that beats
         # one kernel per node (_VoiceProgram.worthwhile), 'always': wherever the graph compiles
         self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)
-        self.specialise = bool(int(os.environ.get('SIG_SPECIALISE', '0'))) if specialise is None else bool(specialise)
+        self.specialise = bool(int(os.environ.get('SIG_SPECIALISE', '0'))) if specialise is None else specialise
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -1832,7 +1833,8 @@ class _VoiceProgram:
             # The launch takes four only with such an image attached, so the choice is made here
             for four in ((True, False) if not filters and self.n_temps == 0 else (False,)):
                 vpl, _ = _native.voice_program_geometry(v, b.N, b.K, CONTEXT, self.depth, C, aligned, specialised=four)
-                if specialise.ensure(self.code, len(oscs), len(params), len(filters), self.n_temps, vpl, C):
+                make = specialise.ensure_in_background if o.specialise == 'background' else specialise.ensure
+                if make(self.code, len(oscs), len(params), len(filters), self.n_temps, vpl, C):
                     label += '*specialised'
                     break
         return o._launch(label, lambda: _native.voice_program(self.code, oscs, params, filters, self.n_temps, self.depth, b.rate, b.pos,
@@ -1865,7 +1867,7 @@ class _VoiceProgram:
         pull path, ~150 us per block)."""
         small_file = (len(self.filters) <= 2 and len(self.oscs) <= 3 and len(self.params) <= 4 and self.n_temps <= 1
                       and self.adsr is None and not self.seeds and not any(op == 'Amp' for op, *_ in self.code))
-        if self.batch.owner.specialise:
+        if self.batch.owner.specialise is True:         # ('background': the interpreter renders meanwhile, so its policy decides)
             # a kernel built for this program has no interpreter to pay for: three filters in series 0.54 T against 0.26 per node,
             # an Amp behind a filter level with it (f64 pow either way)
             from . import specialise

@@ -89,20 +89,65 @@ def ensure(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int,
             return True
         if key in _failed:
             return False
-        try:
-            image = build(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
-            _native.voice_program_attach(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels, image)
-        except (SpecialiseError, _native.NativeError) as e:
+    try:                                                  # (outside the lock: the compiler takes seconds)
+        image = build(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
+        with _lock:
+            if key not in _attached:
+                _native.voice_program_attach(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels, image)
+                _attached.add(key)
+    except (SpecialiseError, _native.NativeError) as e:
+        with _lock:
             _failed.add(key)
-            import warnings
-            warnings.warn(f'voice program not specialised, the interpreter runs it: {e}')
+        import warnings
+        warnings.warn(f'voice program not specialised, the interpreter runs it: {e}')
+        return False
+    return True
+
+
+_pending: dict = {}
+_pool = None
+
+
+def ensure_in_background(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int,
+                         bus_channels: int) -> bool:
+    """`ensure` on a worker thread: True once the kernel is attached, False while it is being built (or cannot be) -- the
+    caller's launches run the interpreter until then, so a real-time sink never waits for the compiler"""
+    global _pool
+    key = (tuple(code), n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
+    with _lock:
+        if key in _attached:
+            return True
+        if key in _failed or key in _pending:
             return False
-        _attached.add(key)
-        return True
+        if _pool is None:
+            import concurrent.futures
+            _pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='sig-specialise')
+        _pending[key] = _pool.submit(_finish, key)
+        return False
+
+
+def _finish(key) -> bool:
+    try:
+        return ensure(list(key[0]), *key[1:])
+    finally:
+        with _lock:
+            _pending.pop(key, None)
+
+
+def wait() -> None:
+    """block until every background build has finished (tests, benchmarks)"""
+    while True:
+        with _lock:
+            futures = list(_pending.values())
+        if not futures:
+            return
+        for f in futures:
+            f.result()
 
 
 def forget() -> None:
     """detach every specialised kernel (tests)"""
+    wait()
     with _lock:
         _native.voice_program_detach_all()
         _attached.clear()

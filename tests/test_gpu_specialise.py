@@ -143,6 +143,32 @@ def test_specialised_kernel_with_the_extended_handlers(which):
     _native.set_voice_program_tuning()
 
 
+def test_background_specialisation_never_blocks_a_render():
+    """specialise='background': the first renders run the interpreter while a worker thread builds the kernel; once it is
+    attached the same renderer's launches use it -- same stream of blocks either way (dev.py:167-179: a sink cannot wait)"""
+    import time
+    from oracle import chain_ref as R
+    from signals_amd import specialise
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N = 64, 256
+    p = E.draw(V, 23)
+    torch.cuda.synchronize()
+    specialise.forget()                                                       # (attached kernels are process-wide: start from none)
+    node, ref_node = E.shapes(p, 'mix_after_filter')
+    ref = R.render_stream(ref_node, 0, N, 6, V)
+    timer = KernelTimer()
+    r = BatchRenderer(node, V, RATE, fuse_program='always', specialise='background', timer=timer)
+    t0 = time.perf_counter()
+    first = r.render(0, N, 3).cpu().numpy()
+    took = time.perf_counter() - t0
+    assert not any(n.endswith('*specialised') for n in names(timer)), (names(timer), took)     # the interpreter rendered these
+    specialise.wait()
+    timer.reset()
+    second = r.render(3 * N, N, 3).cpu().numpy()
+    assert any(n.endswith('*specialised') for n in names(timer)), names(timer)
+    assert maxerr(np.concatenate([first, second]), f32(ref)) < 1e-6 * max(1.0, np.abs(ref).max())
+
+
 def test_switching_attached_kernels_off_and_refusing_a_foreign_image():
     from signals_amd import _native, specialise
     code_a = [('Osc', 2, 0, 0, 0), ('Gain', 0, 0, 0, 0)]
