@@ -12,7 +12,8 @@ for f in *.hip; do
   o="${f%.hip}.o"
   stale=0
   [ -f "$o" ] || stale=1
-  for dep in "$f" sig_common.h sig_osc.h sig_biquad.h sig_adsr.h sig_bus_tile.h sig_mix_tile.h sig_steady.h ../../include/signals_amd.h; do
+  extra=""; [ "$f" = fused_voice_b.hip ] && extra=fused_voice.hip      # (it is that file, compiled for the other waveforms)
+  for dep in "$f" $extra sig_common.h sig_osc.h sig_biquad.h sig_adsr.h sig_bus_tile.h sig_mix_tile.h sig_steady.h ../../include/signals_amd.h; do
     [ "$stale" = 1 ] || { [ "$dep" -nt "$o" ] && stale=1; } || true
   done
   if [ "$stale" = 1 ]; then

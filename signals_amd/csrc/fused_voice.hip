@@ -36,6 +36,24 @@
 #include "sig_osc.h"
 #include "sig_steady.h"
 
+// This file is compiled twice (compile time: 240 walker instantiations + the closed form took 4 min 50 s in one unit):
+// fused_voice.hip itself -- the Sine kernels (walker, closed form) and the C ABI -- and fused_voice_b.hip, which includes it with
+// SIG_FUSED_PART_B -- the walkers of Square, Sawtooth and Triangle behind four plain functions (sig_steady.h: part_b_*).
+// Tuning builds (tools/build_variant.sh -DSIG_TUNE_SINE_ONLY) keep one unit with the Sine kernels and a stereo bus only.
+#if defined(SIG_TUNE_SINE_ONLY)
+#define SIG_FUSED_SPLIT 0
+#define SIG_FUSED_HERE_SINE 1
+#define SIG_FUSED_HERE_OTHERS 0
+#elif defined(SIG_FUSED_PART_B)
+#define SIG_FUSED_SPLIT 1
+#define SIG_FUSED_HERE_SINE 0
+#define SIG_FUSED_HERE_OTHERS 1
+#else
+#define SIG_FUSED_SPLIT 1
+#define SIG_FUSED_HERE_SINE 1
+#define SIG_FUSED_HERE_OTHERS 0
+#endif
+
 namespace {
 
 using namespace sig_fused;
@@ -69,11 +87,6 @@ template <> struct Occ<4> { static constexpr int lo = SIG_FUSED_OCC4 ? SIG_FUSED
 // Bus sums: sig_bus_tile.h (wave-private LDS tile, transposed reduction, per-tile f64 partials + fixed-order tile sum)
 using sig_bus::kPairs;
 using sig_bus::kTileStride;
-
-struct BusArgs {
-    const double* pan; int64_t pan_ld; double* partials; int64_t rows;
-    float* out = nullptr; int64_t out_ld = 0;   // set: the kernel adds the voice tiles itself (sig_bus::sum_tiles_in_workgroup), no partials_kernel launch
-};
 
 __device__ __forceinline__ bool steady_wave(const FusedArgs& a, int v0, int vpt, int64_t p0, int nb);   // below
 
@@ -907,8 +920,10 @@ int64_t steady_consts_offset(int voices, int64_t rows, int bus_channels) {
 
 // Tuning / test hooks.  Product launches read four plain ints; they start from the environment (SIG_FUSED_VPT, _SPAN,
 // _STEADY, _SCAN: read ONCE, when the first launch asks) and tests set them through sig_fused_set_tuning.
-struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1, tile_sum_kernel = 0, mix_f32 = 0; };     // 0 / -1 = the launch heuristics decide
-Tuning& tuning() {
+// (struct Tuning and tuning() are declared in sig_steady.h: ONE instance for both translation units of this file)
+#ifndef SIG_FUSED_PART_B
+}  // namespace
+sig_fused::Tuning& sig_fused::tuning() {
     static Tuning t = [] {
         auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         Tuning u;
@@ -920,6 +935,8 @@ Tuning& tuning() {
     }();
     return t;
 }
+namespace {
+#endif
 
 // Launch geometry (tools/sweep_fused.sh).  Voices per lane: 4 amortises the per-row work shared by a lane's voices
 // (bus staging, loop control) best and leaves room for two waves per SIMD.  Blocks per lane (span): the first
@@ -1009,11 +1026,15 @@ template <int C>
 int dispatch_rows_kind(int kind, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
 {
     switch (kind) {
+#if SIG_FUSED_HERE_SINE
         case SIG_OSC_SINE: return launch_rows<SIG_OSC_SINE, C>(a, bus, out, out_ld, s);
-#ifndef SIG_TUNE_SINE_ONLY
+#endif
+#if SIG_FUSED_HERE_OTHERS
         case SIG_OSC_SQUARE: return launch_rows<SIG_OSC_SQUARE, C>(a, bus, out, out_ld, s);
         case SIG_OSC_SAWTOOTH: return launch_rows<SIG_OSC_SAWTOOTH, C>(a, bus, out, out_ld, s);
         case SIG_OSC_TRIANGLE: return launch_rows<SIG_OSC_TRIANGLE, C>(a, bus, out, out_ld, s);
+#elif SIG_FUSED_SPLIT
+        case SIG_OSC_SQUARE: case SIG_OSC_SAWTOOTH: case SIG_OSC_TRIANGLE: return part_b_rows(C, kind, a, bus, out, out_ld, s);
 #endif
     }
     return (int)hipErrorInvalidValue;
@@ -1080,10 +1101,15 @@ int launch_voice_bus(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipSt
     const int vpt = plan.vpt;
     a.span = plan.span;
     a.steady = plan.steady;
-    if (a.steady) {
-        const int e2 = launch_steady<GAIN, C, false>(a, bus, vpt, out, out_ld, stream);
-        if (e2 || bus.out) return e2;                                          // (the kernel added the voice tiles itself)
-    } else {                                                                   // (Sine with the closed form: that launch did every wave)
+    bool done = false;
+    if constexpr (KIND == SIG_OSC_SINE) {                                      // (the closed form exists for a sinusoid only: not instantiated for the others)
+        if (a.steady) {
+            const int e2 = launch_steady<GAIN, C, false>(a, bus, vpt, out, out_ld, stream);
+            if (e2 || bus.out) return e2;                                      // (the kernel added the voice tiles itself)
+            done = true;
+        }
+    }
+    if (!done) {                                                               // (Sine with the closed form: that launch did every wave)
         const int tiles_w = (a.voices + SIG_WAVE * vpt - 1) / (SIG_WAVE * vpt);
         if (sig_bus::tiles_sum_in_workgroup(tiles_w) && tuning().tile_sum_kernel == 0) { bus.out = out; bus.out_ld = out_ld; }
         const int err = launch_walk<KIND, GAIN, C>(a, bus, vpt, stream);
@@ -1110,11 +1136,15 @@ template <bool GAIN>
 int dispatch_bus_kind(int kind, int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s)
 {
     switch (kind) {
+#if SIG_FUSED_HERE_SINE
         case SIG_OSC_SINE: return dispatch_bus_channels<SIG_OSC_SINE, GAIN>(C, a, bus, out, out_ld, s);
-#ifndef SIG_TUNE_SINE_ONLY
+#endif
+#if SIG_FUSED_HERE_OTHERS
         case SIG_OSC_SQUARE: return dispatch_bus_channels<SIG_OSC_SQUARE, GAIN>(C, a, bus, out, out_ld, s);
         case SIG_OSC_SAWTOOTH: return dispatch_bus_channels<SIG_OSC_SAWTOOTH, GAIN>(C, a, bus, out, out_ld, s);
         case SIG_OSC_TRIANGLE: return dispatch_bus_channels<SIG_OSC_TRIANGLE, GAIN>(C, a, bus, out, out_ld, s);
+#elif SIG_FUSED_SPLIT
+        case SIG_OSC_SQUARE: case SIG_OSC_SAWTOOTH: case SIG_OSC_TRIANGLE: return part_b_bus(GAIN ? 1 : 0, kind, C, a, bus, out, out_ld, s);
 #endif
     }
     return (int)hipErrorInvalidValue;
@@ -1254,11 +1284,15 @@ template <bool GAIN>
 int dispatch_mix_kind(int kind, const FusedArgs& a, hipStream_t s)
 {
     switch (kind) {
+#if SIG_FUSED_HERE_SINE
         case SIG_OSC_SINE: return launch_mix<SIG_OSC_SINE, GAIN>(a, s);
-#ifndef SIG_TUNE_SINE_ONLY
+#endif
+#if SIG_FUSED_HERE_OTHERS
         case SIG_OSC_SQUARE: return launch_mix<SIG_OSC_SQUARE, GAIN>(a, s);
         case SIG_OSC_SAWTOOTH: return launch_mix<SIG_OSC_SAWTOOTH, GAIN>(a, s);
         case SIG_OSC_TRIANGLE: return launch_mix<SIG_OSC_TRIANGLE, GAIN>(a, s);
+#elif SIG_FUSED_SPLIT
+        case SIG_OSC_SQUARE: case SIG_OSC_SAWTOOTH: case SIG_OSC_TRIANGLE: return part_b_mix(GAIN ? 1 : 0, kind, a, s);
 #endif
     }
     return (int)hipErrorInvalidValue;
@@ -1268,17 +1302,44 @@ template <bool GAIN>
 int dispatch_kind(int kind, const FusedArgs& a, hipStream_t s)
 {
     switch (kind) {
+#if SIG_FUSED_HERE_SINE
         case SIG_OSC_SINE: return launch_fused<SIG_OSC_SINE, GAIN>(a, s);
-#ifndef SIG_TUNE_SINE_ONLY
+#endif
+#if SIG_FUSED_HERE_OTHERS
         case SIG_OSC_SQUARE: return launch_fused<SIG_OSC_SQUARE, GAIN>(a, s);
         case SIG_OSC_SAWTOOTH: return launch_fused<SIG_OSC_SAWTOOTH, GAIN>(a, s);
         case SIG_OSC_TRIANGLE: return launch_fused<SIG_OSC_TRIANGLE, GAIN>(a, s);
+#elif SIG_FUSED_SPLIT
+        case SIG_OSC_SQUARE: case SIG_OSC_SAWTOOTH: case SIG_OSC_TRIANGLE: return part_b_chain(GAIN ? 1 : 0, kind, a, s);
 #endif
     }
     return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
+
+#ifdef SIG_FUSED_PART_B
+// the second translation unit of this file (fused_voice_b.hip): Square, Sawtooth and Triangle; what the first one calls for them
+namespace sig_fused {
+int part_b_rows(int C, int kind, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s) {
+    switch (C) {
+        case 0: return dispatch_rows_kind<0>(kind, a, bus, out, out_ld, s);
+        case 1: return dispatch_rows_kind<1>(kind, a, bus, out, out_ld, s);
+        case 2: return dispatch_rows_kind<2>(kind, a, bus, out, out_ld, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+int part_b_bus(int gain, int kind, int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s) {
+    return gain ? dispatch_bus_kind<true>(kind, C, a, bus, out, out_ld, s) : dispatch_bus_kind<false>(kind, C, a, bus, out, out_ld, s);
+}
+int part_b_mix(int gain, int kind, const FusedArgs& a, hipStream_t s) {
+    return gain ? dispatch_mix_kind<true>(kind, a, s) : dispatch_mix_kind<false>(kind, a, s);
+}
+int part_b_chain(int gain, int kind, const FusedArgs& a, hipStream_t s) {
+    return gain ? dispatch_kind<true>(kind, a, s) : dispatch_kind<false>(kind, a, s);
+}
+}  // namespace sig_fused
+#else       // (the C ABI lives in the first translation unit)
 
 extern "C" int sig_fused_osc_biquad(int osc_kind, int filt_type, int32_t rate, int64_t position,
                                     int32_t block_frames, int32_t nblocks, int32_t context, int32_t voices,
@@ -1624,3 +1685,4 @@ extern "C" int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t
                                 phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
                                 bus_channels, workspace, out, out_ld, status, stream, consts, consts_ready);
 }
+#endif  // SIG_FUSED_PART_B

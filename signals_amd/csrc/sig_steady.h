@@ -35,6 +35,20 @@ struct FusedArgs {
     const double* hertz2 = nullptr; int hs2 = 0; const double* phase2 = nullptr; int ps2 = 0; const double* mixrow = nullptr; int ms = 0;
 };
 
+struct BusArgs {
+    const double* pan; int64_t pan_ld; double* partials; int64_t rows;
+    float* out = nullptr; int64_t out_ld = 0;   // set: the kernel adds the voice tiles itself (sig_bus::sum_tiles_in_workgroup), no partials_kernel launch
+};
+
+// Tuning / test hooks of the fused entry points (fused_voice.hip): one instance, read by both of its translation units
+struct Tuning { int vpt = 0, span = 0, steady = -1, scan = -1, tile_sum_kernel = 0, mix_f32 = 0; };     // 0 / -1 = the launch heuristics decide
+Tuning& tuning();
+// fused_voice_b.hip: the walkers of Square / Sawtooth / Triangle, called by fused_voice.hip's dispatchers
+int part_b_rows(int C, int kind, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s);
+int part_b_bus(int gain, int kind, int C, const FusedArgs& a, const BusArgs& bus, float* out, int64_t out_ld, hipStream_t s);
+int part_b_mix(int gain, int kind, const FusedArgs& a, hipStream_t s);
+int part_b_chain(int gain, int kind, const FusedArgs& a, hipStream_t s);
+
 // sin(2 pi f) and cos(2 pi f) in f64 (~1 ulp), any |f| < 2^50: quarter-range reduction by the magic-number
 // rint of sig_osc.h, true 2 pi as hi + lo
 __device__ __forceinline__ double sin2pi(double f) {
