@@ -396,6 +396,75 @@ def gen_small_blocks(out):
     out['small/cascade3/fresh_p1000'] = render(cascade(3), 1000, 256, V)
 
 
+def gen_shapes(out):
+    """Voice graphs beyond the fused kernels' patterns, rendered sequentially in 256-frame blocks from 0 and once on a fresh graph
+    mid-stream: RingMod of two filtered oscillators, a Mix behind a filter, an Amp behind a filter (with its NaN pattern,
+    fx.py:55-60), a node with TWO readers inside the voice (its block cache serves the second, chain/__init__.py:424-457), a
+    cascade with a swept inner cutoff under a tremolo.  What the engine's voice program (one launch per batch) must reproduce."""
+    V = 8
+    vp = voice_params(V, seed=11)
+    rng = np.random.default_rng(12)
+    hz2 = rng.uniform(55, 1760, (1, V))
+    cut1 = np.geomspace(30, 5000, V).reshape(1, V)
+    cut2 = np.geomspace(8000, 200, V).reshape(1, V)
+    mix = np.linspace(0.1, 0.9, V).reshape(1, V)
+    gain = np.linspace(0.3, 1.0, V).reshape(1, V)
+    expo = np.array([[1.0, 2.0, 3.0, 1.5, 0.5, 2.0, 2.5, 1.0]])
+    for k, v in (('hertz', vp['hertz']), ('phase', vp['phase']), ('hertz2', hz2), ('cut1', cut1), ('cut2', cut2), ('mix', mix),
+                 ('gain', gain), ('expo', expo)):
+        out[f'shapes/{k}'] = v
+
+    def saw():
+        o = osc.Sawtooth(); o.hertz = fix(vp['hertz']); o.phase = fix(vp['phase'])
+        return o
+
+    def tri():
+        o = osc.Triangle(); o.hertz = fix(hz2)
+        return o
+
+    def filt(cls, src, cut):
+        f = cls(); f.input = src; f.cutoff = cut if isinstance(cut, chain.Emitter) else fix(cut)
+        return f
+
+    def lfo(hz, depth, centre):
+        o = osc.Sine(); o.hertz = fix([[hz]])
+        m = fx.Mix(); m.left = o; m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r = fx.RingMod(); r.left = m; r.right = fix(centre)
+        return r
+
+    def ringmod():
+        n = fx.RingMod(); n.left = filt(fx.LowPass, saw(), cut1); n.right = filt(fx.HighPass, tri(), cut2)
+        return n
+
+    def mix_after_filter():
+        n = fx.Mix(); n.left = filt(fx.HighPass, saw(), cut1); n.right = tri(); n.mix = fix(mix)
+        return n
+
+    def amp():
+        a = fx.Amp(); a.left = filt(fx.LowPass, saw(), cut2); a.right = fix(expo)
+        g = fx.Gain(); g.left = a; g.right = fix(gain)
+        return g
+
+    def fanout():
+        shared = filt(fx.LowPass, saw(), cut1)
+        rm = fx.RingMod(); rm.left = shared; rm.right = tri()
+        n = fx.Mix(); n.left = shared; n.right = rm; n.mix = fix(mix)
+        return n
+
+    def swept_cascade():
+        inner = filt(fx.LowPass, saw(), lfo(1.7, 0.4, cut2))
+        outer = filt(fx.LowPass, inner, cut1 * 4.0)
+        g = fx.Gain(); g.left = outer; g.right = lfo(3.1, 0.3, gain)
+        return g
+
+    for name, build in (('ringmod', ringmod), ('mix', mix_after_filter), ('amp', amp), ('fanout', fanout), ('swept_cascade', swept_cascade)):
+        p = Probe()
+        p.input = build()
+        with np.errstate(invalid='ignore'):
+            out[f'shapes/{name}/n256_p0'] = np.concatenate([np.array(p.input.request(loc(b * 256, 256, V))) for b in range(6)])
+            out[f'shapes/{name}/fresh_p1000'] = render(build(), 1000, 256, V)
+
+
 def gen_pairs(out):
     """A filter reading TWO oscillators through Mix / RingMod (fx.py:35-46), and a Gain in front of a filter: the
     topologies round 2's fuser folds into one launch; rendered sequentially."""
@@ -567,8 +636,11 @@ def main():
     groups = {
         'osc': gen_osc, 'filter': gen_filter, 'cascade': gen_cascade, 'effects': gen_effects,
         'sigs': gen_sigs_topologies, 'c2': gen_c2, 'blockloc': gen_blockloc, 'modulated': gen_modulated, 'pairs': gen_pairs,
-        'small': gen_small_blocks,
+        'small': gen_small_blocks, 'shapes': gen_shapes,
     }
+    only = sys.argv[1:]                                    # python tests/golden/gen_golden.py [group ...]: only those groups
+    if only:
+        groups = {k: v for k, v in groups.items() if k in only}
     meta = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                 rate=RATE, reference='/root/reference (noah-aviel-dove/signals @ v1)',
                 note='outputs are float64 exactly as the reference returned them')
@@ -578,7 +650,8 @@ def main():
         path = HERE / f'{name}.npz'
         np.savez_compressed(path, **{k.replace('/', '__'): v for k, v in out.items()})
         print(f'{path.name}: {len(out)} arrays, {path.stat().st_size / 1024:.0f} KiB')
-    (HERE / 'META.json').write_text(json.dumps(meta, indent=1) + '\n')
+    if not only:
+        (HERE / 'META.json').write_text(json.dumps(meta, indent=1) + '\n')
 
 
 if __name__ == '__main__':

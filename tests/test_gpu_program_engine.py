@@ -287,3 +287,62 @@ def test_short_block_fixtures_of_the_reference(golden, N):
             got = render_batches(cascade(3), V, 0, 256, (2, 1, 3), fuse_program=mode)
             assert maxerr(got, f32(g['small/cascade3/n256_p0'])) < 1e-6, mode
             assert maxerr(render_batches(cascade(3), V, 1000, 256, (1,), fuse_program=mode), f32(g['small/cascade3/fresh_p1000'])) < 1e-6, mode
+
+
+@pytest.mark.parametrize('name', ['ringmod', 'mix', 'amp', 'fanout', 'swept_cascade'])
+def test_voice_graph_fixtures_of_the_reference(golden, name):
+    """tests/golden/shapes.npz -- OUTPUTS OF THE REFERENCE ITSELF for graphs beyond the fused kernels' patterns (RingMod of two
+    filtered oscillators, Mix and Amp behind a filter, a node with two readers, a swept cascade under a tremolo; six 256-frame
+    blocks from 0 and a fresh graph at 1000): the engine's schedules -- default policy, every graph forced through the
+    interpreted launch, and the kernel specialised for the program -- within 1e-6, whatever the batching"""
+    from signals_amd import specialise
+    from signals_amd.chain import fx
+    from signals_amd.engine import KernelTimer
+    g = golden('shapes')
+    F = lambda k: fix(g[f'shapes/{k}'])
+    V = g['shapes/hertz'].shape[1]
+    saw = lambda: mkosc('Sawtooth', g['shapes/hertz'], g['shapes/phase'])
+    tri = lambda: mkosc('Triangle', g['shapes/hertz2'])
+
+    def filt(cls, src, cut):
+        f = cls(); f.input = src; f.cutoff = cut
+        return f
+
+    def lfo(hz, depth, centre):
+        m = fx.Mix(); m.left = mkosc('Sine', [[hz]]); m.right = fix([[1.0]]); m.mix = fix([[depth]])
+        r = fx.RingMod(); r.left = m; r.right = fix(centre)
+        return r
+
+    def build():
+        if name == 'ringmod':
+            n = fx.RingMod(); n.left = filt(fx.LowPass, saw(), F('cut1')); n.right = filt(fx.HighPass, tri(), F('cut2'))
+        elif name == 'mix':
+            n = fx.Mix(); n.left = filt(fx.HighPass, saw(), F('cut1')); n.right = tri(); n.mix = F('mix')
+        elif name == 'amp':
+            a = fx.Amp(); a.left = filt(fx.LowPass, saw(), F('cut2')); a.right = F('expo')
+            n = fx.Gain(); n.left = a; n.right = F('gain')
+        elif name == 'fanout':
+            shared = filt(fx.LowPass, saw(), F('cut1'))
+            rm = fx.RingMod(); rm.left = shared; rm.right = tri()
+            n = fx.Mix(); n.left = shared; n.right = rm; n.mix = F('mix')
+        else:
+            inner = filt(fx.LowPass, saw(), lfo(1.7, 0.4, g['shapes/cut2']))
+            outer = filt(fx.LowPass, inner, fix(g['shapes/cut1'] * 4.0))
+            n = fx.Gain(); n.left = outer; n.right = lfo(3.1, 0.3, g['shapes/gain'])
+        return n
+    ref, fresh = g[f'shapes/{name}/n256_p0'], g[f'shapes/{name}/fresh_p1000']
+    scale = max(1.0, float(np.nanmax(np.abs(ref))))
+    modes = [dict(), dict(fuse_program='always'), dict(fuse_program=False)]
+    if specialise.hipcc() is not None:
+        modes.append(dict(fuse_program='always', specialise=True))
+    for kw in modes:
+        timer = KernelTimer()
+        got = render_batches(build(), V, 0, 256, (2, 3, 1), timer, **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (name, kw)           # (Amp: NaN where the reference has NaN)
+        assert maxerr(got, f32(ref)) < 1e-6 * scale, (name, kw)
+        if kw.get('fuse_program') == 'always':
+            assert any(n.startswith('voice_program[') for n in launches(timer)), (name, launches(timer))
+        if kw.get('specialise'):
+            assert any(n.endswith('*specialised') for n in launches(timer)), (name, launches(timer))
+        got = render_batches(build(), V, 1000, 256, (1,), **kw)
+        assert np.array_equal(np.isnan(got), np.isnan(fresh)) and maxerr(got, f32(fresh)) < 1e-6 * scale, (name, kw)

@@ -278,6 +278,43 @@ def test_blocks_no_longer_than_the_filter_context(golden, N):
         assert same(R.render(cascade(3), 1000, 256, ref.shape[1]), g['small/cascade3/fresh_p1000'])
 
 
+def shape_voices(g):
+    """oracle graphs of tests/golden/shapes.npz (gen_golden.py: gen_shapes), by name"""
+    F = lambda k: R.Fixed(g[f'shapes/{k}'])
+    saw = lambda: R.Osc('Sawtooth', F('hertz'), F('phase'))
+    tri = lambda: R.Osc('Triangle', F('hertz2'))
+
+    def lfo(hz, depth, centre):
+        return R.Binary('RingMod', R.Binary('Mix', R.Osc('Sine', R.Fixed([[hz]])), R.Fixed([[1.0]]), R.Fixed([[depth]])), R.Fixed(centre))
+
+    def fanout():
+        shared = R.Filter('lp', saw(), F('cut1'))                             # ONE node, two readers: the second is served by its block cache
+        return R.Binary('Mix', shared, R.Binary('RingMod', shared, tri()), F('mix'))
+    return {
+        'ringmod': lambda: R.Binary('RingMod', R.Filter('lp', saw(), F('cut1')), R.Filter('hp', tri(), F('cut2'))),
+        'mix': lambda: R.Binary('Mix', R.Filter('hp', saw(), F('cut1')), tri(), F('mix')),
+        'amp': lambda: R.Binary('Gain', R.Binary('Amp', R.Filter('lp', saw(), F('cut2')), F('expo')), F('gain')),
+        'fanout': fanout,
+        'swept_cascade': lambda: R.Binary('Gain', R.Filter('lp', R.Filter('lp', saw(), lfo(1.7, 0.4, g['shapes/cut2'])),
+                                                           R.Fixed(g['shapes/cut1'] * 4.0)), lfo(3.1, 0.3, g['shapes/gain'])),
+    }
+
+
+@pytest.mark.parametrize('name', ['ringmod', 'mix', 'amp', 'fanout', 'swept_cascade'])
+def test_voice_graphs_beyond_the_fused_patterns(golden, name):
+    """RingMod of two filtered oscillators, a Mix and an Amp behind a filter (fx.py:35-60 over fx.py:85-121), a node with two
+    readers (chain/__init__.py:424-457), a swept cascade under a tremolo -- six 256-frame blocks from 0 and a fresh graph at
+    1000, as the REFERENCE rendered them: the oracle reproduces every array bit for bit (Amp's NaN pattern included)"""
+    g = golden('shapes')
+    build = shape_voices(g)[name]
+    with np.errstate(invalid='ignore'):
+        ref = g[f'shapes/{name}/n256_p0']
+        assert same(R.render_stream(build(), 0, 256, 6, ref.shape[1]), ref), name
+        assert same(R.render(build(), 1000, 256, ref.shape[1]), g[f'shapes/{name}/fresh_p1000']), name
+    if name == 'amp':
+        assert np.isnan(ref).any() and np.isfinite(ref).any()
+
+
 def test_blockloc_table(golden):
     for pos, n, bp, bf, ap, af, fr0, fr1, b_le, l_le, r_le in golden('blockloc')['blockloc/table']:
         assert R.before(int(pos), int(n), 100) == (bp, bf)
