@@ -399,6 +399,28 @@ def run_modulated(K: int = 1024, steps: int = 30, prewarm_s: float = 0.5) -> dic
                                 'value': V * N * K * steps / dt / 1e6, 'ms_per_step': dt / steps * 1e3,
                                 'max_abs_error_blocks_0_1': err, 'full_scale': float(np.max(np.abs(ref))),
                                 'launches_per_step': {k: round(v['ms'] / v['calls'], 4) for k, v in summ.items()}}
+        # the same leg with the control program's kernel built for this graph's program (BatchRenderer(specialise=True): hipcc at
+        # the first render, then the disk cache): registers in VGPRs instead of an LDS file behind an interpretive loop
+        timer = KernelTimer(sample_every=4)
+        r = BatchRenderer(cfg.c2_modulated_graph(p, kind, vibrato, sweep, tremolo), 2, RATE, timer=timer, specialise=True)
+        first = r.render(0, N, K)
+        err = float(np.max(np.abs(first[:2 * N].double().cpu().numpy() - ref)))
+        pos = N * K
+        t_end = time.perf_counter() + prewarm_s / 2
+        while time.perf_counter() < t_end:
+            r.render(pos, N, K); pos += N * K
+            torch.cuda.synchronize()
+        timer.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render(pos, N, K); pos += N * K
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        summ = timer.summary()
+        if any(k.endswith('*specialised') for k in summ):
+            out['voices'][label]['specialised'] = {'value': V * N * K * steps / dt / 1e6, 'ms_per_step': dt / steps * 1e3,
+                                                   'max_abs_error_blocks_0_1': err,
+                                                   'launches_per_step': {k: round(v['ms'] / v['calls'], 4) for k, v in summ.items()}}
     return out
 
 

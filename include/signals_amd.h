@@ -303,6 +303,19 @@ int sig_control_program(int32_t rate, int64_t position, int32_t step, int32_t nb
                         int64_t min_position,
                         const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream);
 
+/* SPECIALISED control programs: signals_amd/csrc/control_program.hip built as a gfx950 code object for one program STRUCTURE
+ * (macros SIG_CTL_STATIC_INS = {{op, kind, a, b, c, dst, wide}, ...} in evaluation order and SIG_CTL_STATIC_OUTS = {{reg, wide},
+ * ...}; `hipcc --genco`, signals_amd/specialise.py): the registers are VGPRs instead of an LDS file behind an interpretive loop.
+ * `description` = [n_ins, n_outs, the seven words per instruction, the two per output]; the image must describe itself the same
+ * way (its sig_ctl_specialised_info kernel) or hipErrorInvalidImage.  A set-up call (allocates, launches, synchronises); the
+ * handle (>= 1) is valid for the life of the process.  sig_control_program_attached = sig_control_program through that kernel:
+ * the CALLER vouches that `program` / `outs` have the structure the handle was built for (they are device memory, the library
+ * cannot look); row pointers, strides and output pointers are read from them as usual.  The same values, bit for bit. */
+int sig_control_program_attach(const int32_t* description, int32_t n_words, const void* image, int32_t* handle);
+int sig_control_program_attached(int32_t handle, int32_t rate, int64_t position, int32_t step, int32_t nblocks, int32_t cols,
+                                 int64_t front_position, int64_t min_position,
+                                 const sig_ctl_ins* program, int32_t n_ins, const sig_ctl_out* outs, int32_t n_outs, void* stream);
+
 /* Fused voice chain + dense mix matrix:  out[n, 64g : 64g+64] = ([gain *] Filter(Osc))[n, 64g : 64g+64] @ matrix
  * -- Osc._eval (chain/osc.py:26-62), CritFilter._filter (chain/fx.py:85-121), Gain._eval (chain/fx.py:49-52) and the
  * build-defined MixMatrix, i.e. the chain of sig_fused_osc_biquad feeding sig_mix_matrix (BASELINE config 5) without the per-voice rows going

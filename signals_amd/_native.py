@@ -34,7 +34,8 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_osc_biquad_rows', 'sig_fused_voice_bus_rows', 'sig_fused_osc_pair_biquad', 'sig_fused_voice_pair_bus',
            'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
            'sig_voice_program', 'sig_voice_program_set_tuning', 'sig_voice_program_geometry', 'sig_voice_program_args_size',
-           'sig_voice_program_attach', 'sig_voice_program_detach_all', 'sig_voice_program_use_attached')
+           'sig_voice_program_attach', 'sig_voice_program_detach_all', 'sig_voice_program_use_attached',
+           'sig_control_program_attach', 'sig_control_program_attached')
 
 
 class NativeError(RuntimeError):
@@ -184,6 +185,10 @@ def lib() -> ctypes.CDLL:
                                              dp, i32, i32, dp, dp, i32, i32, dp, dp, i32, i32, dp, i32, i32, dp, i64, i32, vp, vp, i64, vp, vp]
         L.sig_control_program.restype = ctypes.c_int
         L.sig_control_program.argtypes = [i32, i64, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp]
+        L.sig_control_program_attach.restype = ctypes.c_int
+        L.sig_control_program_attach.argtypes = [ctypes.POINTER(i32), i32, ctypes.c_char_p, ctypes.POINTER(i32)]
+        L.sig_control_program_attached.restype = ctypes.c_int
+        L.sig_control_program_attached.argtypes = [i32, i32, i64, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp]
         L.sig_voice_program.restype = ctypes.c_int
         L.sig_voice_program.argtypes = [ctypes.POINTER(VoiceProgramT), i32, i64, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int64), i32,
                                         dp, i64, i32, vp, vp, i64, vp, vp]
@@ -863,6 +868,34 @@ def control_program(rate: int, position: int, step: int, nblocks: int, cols: int
     _gpu(program, outs)
     _check(lib().sig_control_program(rate, position, step, nblocks, cols, front_position, min_position, program.data_ptr(), n_ins,
                                      outs.data_ptr(), n_outs, _stream(program)), 'sig_control_program')
+
+
+def control_program_description(ins: list, outs: list) -> list:
+    """what a specialised build of control_program.hip is keyed by: [n_ins, n_outs, (op, kind, a, b, c, dst, wide) per
+    instruction, (reg, wide) per output] -- the program's structure without its pointers (CtlIns / CtlOut lists)"""
+    words = [len(ins), len(outs)]
+    for x in ins:
+        words += [x.op, x.kind, x.a, x.b, x.c, x.dst, 1 if x.cols > 1 else 0]
+    for o in outs:
+        words += [o.reg, 1 if o.cols > 1 else 0]
+    return words
+
+
+def control_program_attach(description: list, image: bytes) -> int:
+    """hand the library a build of control_program.hip specialised for this structure; returns the handle to launch it with"""
+    arr = (ctypes.c_int32 * len(description))(*description)
+    handle = ctypes.c_int32(0)
+    _check(lib().sig_control_program_attach(arr, len(description), image, ctypes.byref(handle)), 'sig_control_program_attach')
+    return handle.value
+
+
+def control_program_attached(handle: int, rate: int, position: int, step: int, nblocks: int, cols: int, program: torch.Tensor,
+                             n_ins: int, outs: torch.Tensor, n_outs: int, front_position: int = -1, min_position: int = 0) -> None:
+    """`control_program` through the specialised kernel behind `handle` (same arguments, same values)"""
+    _gpu(program, outs)
+    _check(lib().sig_control_program_attached(handle, rate, position, step, nblocks, cols, front_position, min_position,
+                                              program.data_ptr(), n_ins, outs.data_ptr(), n_outs, _stream(program)),
+           'sig_control_program_attached')
 
 
 def fused_voice_bus_plan(kind: str, position: int, voices: int, block_frames: int, nblocks: int, context: int) -> dict:

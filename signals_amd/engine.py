@@ -460,6 +460,7 @@ class _ControlProgram:
         for o in outs:
             o.reg = new_of[o.reg]
         self.n_ins, self.n_outs = len(self.ins), len(outs)
+        self.description = _native.control_program_description(self.ins, outs)     # (its structure: what a specialised kernel is built for)
         self.program_t = _native.upload_structs(self.ins) if self.ins else None
         self.outs_t = _native.upload_structs(outs) if outs else None
 
@@ -510,9 +511,19 @@ class _ControlProgram:
     def run(self, owner, rate: int, position: int, step: int, front_position: int = -1, min_position: int = 0):
         """the K-row replies; with `front_position` also the (1, cols) replies at that position -> (rows, fronts)"""
         if self.n_outs:
-            owner._launch('control_program[block-rate]',
-                          lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
-                                                          self.outs_t, self.n_outs, front_position, min_position), units=self.K * self.cols)
+            handle = None
+            if owner.specialise:                              # the kernel built for this program's structure (signals_amd/specialise.py)
+                from . import specialise
+                handle = specialise.ensure_control(self.description, background=owner.specialise == 'background')
+            if handle is not None:
+                owner._launch('control_program[block-rate]*specialised',
+                              lambda: _native.control_program_attached(handle, rate, position, step, self.K, self.cols, self.program_t,
+                                                                       self.n_ins, self.outs_t, self.n_outs, front_position, min_position),
+                              units=self.K * self.cols)
+            else:
+                owner._launch('control_program[block-rate]',
+                              lambda: _native.control_program(rate, position, step, self.K, self.cols, self.program_t, self.n_ins,
+                                                              self.outs_t, self.n_outs, front_position, min_position), units=self.K * self.cols)
         rows = [as_control(src.resident()) if r is None else r for src, r in zip(self.srcs, self.results)]
         if any(t.shape[0] not in (1, self.K) or (r is None and t.shape[0] != 1) for t, r in zip(rows, self.results)):
             raise NotBatchable('multi-row Fixed on a control port')             # (edited since the program was compiled)

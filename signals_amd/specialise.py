@@ -21,7 +21,7 @@ from . import _native
 
 CSRC = pathlib.Path(__file__).resolve().parent / 'csrc'
 CACHE = pathlib.Path(os.environ.get('SIG_SPECIALISE_CACHE') or pathlib.Path(__file__).resolve().parent / '_specialised')
-SOURCES = ('voice_program.hip', 'sig_adsr.h', 'sig_biquad.h', 'sig_bus_tile.h', 'sig_osc.h', 'sig_common.h', '../../include/signals_amd.h')
+SOURCES = ('voice_program.hip', 'control_program.hip', 'sig_adsr.h', 'sig_biquad.h', 'sig_bus_tile.h', 'sig_osc.h', 'sig_common.h', '../../include/signals_amd.h')
 
 _attached: set = set()
 _failed: set = set()
@@ -55,29 +55,89 @@ def flags(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, 
             f'-DSIG_VP_STATIC_WAVES={ {1: 3, 2: 2, 4: 1}[voices_per_lane] }']
 
 
-def build(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bytes:
-    """the code object (gfx950) of voice_program.hip specialised for this program; cached on disk"""
-    defs = flags(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels)
-    key = hashlib.sha1((_source_digest() + ' '.join(defs)).encode()).hexdigest()[:24]
-    path = CACHE / f'vp_{key}.hsaco'
+def _compile(source: str, defs: list, prefix: str) -> bytes:
+    """`source` (a file of signals_amd/csrc) built as a gfx950 code object with these macros; cached on disk"""
+    key = hashlib.sha1((_source_digest() + source + ' '.join(defs)).encode()).hexdigest()[:24]
+    path = CACHE / f'{prefix}_{key}.hsaco'
     if path.exists():
         return path.read_bytes()
     cc = hipcc()
     if cc is None:
-        raise SpecialiseError('hipcc not found (set HIPCC): voice programs stay on the interpreter')
+        raise SpecialiseError('hipcc not found (set HIPCC): the interpreters keep running')
     try:
         CACHE.mkdir(parents=True, exist_ok=True)
         tmp = path.with_suffix(f'.{os.getpid()}.{threading.get_ident()}.tmp')
         cmd = [cc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-Wno-unused-function', '--genco', *defs,
-               '-o', str(tmp), str(CSRC / 'voice_program.hip')]
+               '-I', str(CSRC.parent.parent / 'include'), '-o', str(tmp), str(CSRC / source)]
         done = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         if done.returncode != 0 or not tmp.exists():
             tmp.unlink(missing_ok=True)
-            raise SpecialiseError(f'hipcc failed on the specialised voice program:\n{done.stderr[-2000:]}')
+            raise SpecialiseError(f'hipcc failed on the specialised {source}:\n{done.stderr[-2000:]}')
         os.replace(tmp, path)                             # (atomic: another process may be building the same image)
         return path.read_bytes()
     except (OSError, subprocess.TimeoutExpired) as e:     # a read-only package directory, a compiler that cannot be started ...
-        raise SpecialiseError(f'specialised voice program not built: {e}') from e
+        raise SpecialiseError(f'specialised {source} not built: {e}') from e
+
+
+def build(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bytes:
+    """the code object (gfx950) of voice_program.hip specialised for this program; cached on disk"""
+    return _compile('voice_program.hip', flags(code, n_oscs, n_params, n_filters, n_temps, voices_per_lane, bus_channels), 'vp')
+
+
+# ---- block-rate control programs (control_program.hip): the same idea, keyed by the program's STRUCTURE (ops, register indices,
+# which instructions and outputs are wide); row and output pointers stay run-time arguments
+_ctl_handles: dict = {}
+
+
+def control_flags(description: list) -> list:
+    n_ins, n_outs = description[0], description[1]
+    ins = [description[2 + 7 * k: 2 + 7 * k + 7] for k in range(n_ins)]
+    outs = [description[2 + 7 * n_ins + 2 * k: 2 + 7 * n_ins + 2 * k + 2] for k in range(n_outs)]
+    braces = lambda rows: '{' + ','.join('{' + ','.join(str(int(w)) for w in row) + '}' for row in rows) + '}'
+    return [f'-DSIG_CTL_STATIC_INS={braces(ins)}', f'-DSIG_CTL_STATIC_OUTS={braces(outs)}']
+
+
+def ensure_control(description: list, background: bool = False):
+    """the handle of the kernel specialised for this control-program structure (built and attached once per process), or None
+    while it is not available (no hipcc, a failed build, or -- `background` -- still being built)"""
+    key = tuple(description)
+    with _lock:
+        if key in _ctl_handles:
+            return _ctl_handles[key]
+        if key in _failed or key in _pending:
+            return None
+    if description[0] == 0 or description[1] == 0:
+        return None
+
+    def make():
+        try:
+            image = _compile('control_program.hip', control_flags(description), 'ctl')
+            handle = _native.control_program_attach(list(description), image)
+        except (SpecialiseError, _native.NativeError) as e:
+            with _lock:
+                _failed.add(key)
+            import warnings
+            warnings.warn(f'control program not specialised, the interpreter runs it: {e}')
+            return None
+        with _lock:
+            _ctl_handles[key] = handle
+        return handle
+    if not background:
+        return make()
+    global _pool
+    with _lock:
+        if _pool is None:
+            import concurrent.futures
+            _pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='sig-specialise')
+
+        def job():
+            try:
+                return make()
+            finally:
+                with _lock:
+                    _pending.pop(key, None)
+        _pending[key] = _pool.submit(job)
+    return None
 
 
 def ensure(code: list, n_oscs: int, n_params: int, n_filters: int, n_temps: int, voices_per_lane: int, bus_channels: int) -> bool:

@@ -143,6 +143,52 @@ def test_specialised_kernel_with_the_extended_handlers(which):
     _native.set_voice_program_tuning()
 
 
+def test_specialised_control_program_gives_the_interpreters_bits():
+    """control_program.hip built for one program's structure (registers in VGPRs instead of an LDS file behind an interpretive
+    loop): a subgraph with every waveform, Gain / Mix / RingMod / Amp, one-column and V-wide rows, a shared sub-expression --
+    several ports at once, K = 1 and K = 37, mid-stream positions, the block in front of a batch -- bit for bit what
+    sig_control_program writes (forward_at_block_rate, chain/__init__.py:305-306; osc.py:26-62; fx.py:35-60)"""
+    from helpers import fix, mkosc
+    from signals_amd import SignalFlags
+    from signals_amd.chain import Receiver, fx, port
+    from signals_amd.engine import BatchRenderer, KernelTimer, _Batch
+    rng = np.random.default_rng(5)
+    V = 300
+    wide, wide2 = rng.uniform(0.2, 2.0, (1, V)), rng.uniform(-1.0, 1.0, (1, V))
+    lfo = mkosc('Sine', [[1.3]])
+    tri = mkosc('Triangle', rng.uniform(0.5, 9.0, (1, V)), rng.uniform(0, 1, (1, V)))
+    sq = mkosc('Square', [[0.7]], [[0.1]])
+    saw = mkosc('Sawtooth', [[2.9]])
+    scaled = fx.Gain(); scaled.left = lfo; scaled.right = fix([[0.4]])
+    offset = fx.Mix(); offset.left = scaled; offset.right = fix(wide); offset.mix = fix([[0.25]])
+    prod = fx.RingMod(); prod.left = offset; prod.right = tri
+    amp = fx.Amp(); amp.left = prod; amp.right = fix([[1.5]])
+    shared = fx.Mix(); shared.left = scaled; shared.right = sq; shared.mix = fix(np.abs(wide2))
+    hole = fx.RingMod(); hole.left = saw
+
+    class Ports(Receiver):
+        a = port('a'); b = port('b'); c = port('c'); d = port('d')
+        HOST_ARRAYS = False
+
+        @classmethod
+        def flags(cls):
+            return SignalFlags(0)
+    host = Ports()
+    host.a, host.b, host.c, host.d = amp, shared, hole, lfo
+    ports = [host.a, host.b, host.c, host.d]
+    plain, timer = BatchRenderer(lfo, 1, RATE), KernelTimer()
+    special = BatchRenderer(lfo, 1, RATE, specialise=True, timer=timer)
+    for pos, N, K in ((0, 256, 37), (48000 * 3 + 17, 128, 1), (999, 64, 5)):
+        for front in (-1, max(pos - 100, 0)):
+            want = _Batch(plain, pos, N, K, False)._control_many(ports, front)
+            got = _Batch(special, pos, N, K, False)._control_many(ports, front)
+            torch.cuda.synchronize()
+            for group_w, group_g in (((want, got),) if front < 0 else zip(want, got)):
+                for name, x, y in zip('abcd', group_w, group_g):
+                    assert x.shape == y.shape and np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), (name, pos, N, K, front)
+    assert any(n == 'control_program[block-rate]*specialised' for n in names(timer)), names(timer)
+
+
 def test_background_specialisation_never_blocks_a_render():
     """specialise='background': the first renders run the interpreter while a worker thread builds the kernel; once it is
     attached the same renderer's launches use it -- same stream of blocks either way (dev.py:167-179: a sink cannot wait)"""
