@@ -30,7 +30,8 @@ FAMILY = {'fused_walk_kernel': 'fused_voice_bus', 'fused_steady_bus_kernel': 'fu
           'osc_bank_kernel': 'osc_bank', 'biquad_coldstart_kernel': 'biquad_coldstart', 'biquad_walk_kernel': 'biquad_coldstart',
           'ew_fast_kernel': 'elementwise', 'fused_scan_kernel': 'fused_scan', 'fused_cascade_kernel': 'fused_cascade_bus',
           'mix_matrix_kernel': 'mix_matrix', 'biquad_bus_kernel': 'biquad_bus', 'fused_steady_mix_kernel': 'fused_osc_biquad_mix',
-          'control_program_kernel': 'control_program', 'voice_program_kernel': 'voice_program', 'sig_vp_specialised': 'voice_program_specialised'}
+          'control_program_kernel': 'control_program', 'voice_program_kernel': 'voice_program', 'sig_vp_specialised': 'voice_program_specialised',
+          'sig_ctl_specialised': 'control_program_specialised'}
 SUMMED = ('fused_voice_bus', 'fused_cascade_bus')
 FIELDS = ['Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'Counter_Name', 'Counter_Value',
           'Start_Timestamp', 'End_Timestamp']
@@ -92,7 +93,7 @@ def main(tag, rnd):
             if what == 'configs':            # tools/measure_configs.py: C3 = cascade kernel + its tile sum, C5 = the walker with the MFMA sink
                 key = {'fused_cascade_kernel': 'C3/fused_cascade_bus', 'partials_kernel': 'C3/fused_cascade_bus',
                        'fused_walk_kernel': 'C2_modulated/fused_voice_bus', 'control_program_kernel': 'C2_modulated/control_program',
-                       'fused_steady_bus_kernel': 'C2_sine_sweep/fused_voice_bus', 'voice_program_kernel': 'programs/voice_program', 'sig_vp_specialised': 'programs/voice_program_specialised',
+                       'fused_steady_bus_kernel': 'C2_sine_sweep/fused_voice_bus', 'voice_program_kernel': 'programs/voice_program', 'sig_vp_specialised': 'programs/voice_program_specialised', 'sig_ctl_specialised': 'C2_modulated/control_program_specialised',
                        'fused_steady_mix_kernel': 'C5/fused_osc_biquad_mix'}.get(k, 'configs/' + fam)
             if fam in SUMMED and what != 'configs':
                 traffic[key] = (traffic.get(key, 0) if first[key] else 0) + int((2 * f + w) * 1024)

@@ -88,3 +88,4 @@ if __name__ == '__main__':
     run('C2 Sine voices with cutoff sweep + tremolo', c2s, 1024, steps)
     run('RingMod of two filtered oscillators (voice program)', vp, 1024, steps)
     run('RingMod of two filtered oscillators (kernel specialised for the program)', vp, 1024, steps, specialise=True)
+    run('C2 voices with vibrato + cutoff sweep + tremolo (control program specialised)', c2m, 1024, steps, specialise=True)
