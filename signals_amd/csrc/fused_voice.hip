@@ -993,9 +993,11 @@ int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_
             BusPlan plan = plan_voice_bus(a, KIND);
             if (plan.steady) {
                 if (plan.vpt > 8) plan.vpt = 8;
-                // per-block constants: 4 voices per lane (at 8 the per-span oscillator parts push the kernel past 512 registers, and
-                // the spills around every block's set-up cost 20 us of scratch round trips per block); tuning hook: as forced
-                if (!gain_only && plan.vpt > 4 && tuning().vpt == 0) plan.vpt = 4;
+                // per-block constants: 2 voices per lane (at 8 the per-span oscillator parts push the kernel past 512 registers, and
+                // the spills around every block's set-up cost 20 us of scratch round trips per block; at 4 it needs 335 and runs one
+                // wave per SIMD, whose long dependent chains -- divisions, square roots, polynomials -- nothing overlaps: 195
+                // registers at 2 leave room for a second wave, 131 -> 122 us per 1024 blocks); tuning hook: as forced
+                if (!gain_only && plan.vpt > 2 && tuning().vpt == 0) plan.vpt = 2;
                 a.span = plan.span;
                 a.steady = 1;
                 // a swept cutoff (with or without a tremolo): per-(block, voice) filter constants; a tremolo alone: the bus
