@@ -202,9 +202,19 @@ __device__ __forceinline__ BlockVoice steady_block_constants(int type, double ra
     const M2 Mss = {fma(PE.im, alpha, PE.re), PE.im * o.beta, fma(QE.im, alpha, QE.re), QE.im * o.beta};
     M2 Ac;                                                                     // A^c by squaring
     const M2 A1 = {-a1, 1.0, -a2, 0.0};
-    if (c == 100) {                                                            // the reference's context (fx.py:82-83): 100 = 64 + 32 + 4, straight-line
-        const M2 A2 = m2_mul(A1, A1), A4 = m2_mul(A2, A2), A8 = m2_mul(A4, A4), A16 = m2_mul(A8, A8), A32 = m2_mul(A16, A16);
-        Ac = m2_mul(m2_mul(m2_mul(A32, A32), A32), A4);
+    if (c == 100) {
+        // the reference's context (fx.py:82-83).  Cayley-Hamilton: A^2 = tr A - det I (tr = -a1, det = a2), so every power is
+        // p A + q I and squaring / multiplying by A act on the two scalars: (p, q)^2 = (p (p tr + 2 q), q^2 - p^2 det),
+        // (p, q) A = (p tr + q, -p det).  100 = 1100100b: 6 squarings + 2 multiplications, ~40 operations instead of the 64 of
+        // eight 2x2 products
+        const double tr = -a1, det = a2;
+        double pw = 1.0, qw = 0.0;                                             // A^1
+        auto sq = [&]() { const double t = fma(pw, tr, qw + qw), pp = pw * pw; qw = fma(qw, qw, -(pp * det)); pw = pw * t; };
+        auto ma = [&]() { const double t = fma(pw, tr, qw); qw = -(pw * det); pw = t; };
+        sq(); ma();                                                            // A^3
+        sq(); sq(); sq(); ma();                                                // A^25
+        sq(); sq();                                                            // A^100
+        Ac = M2{fma(pw, -a1, qw), pw, -a2 * pw, qw};
     } else {
         Ac = M2{1.0, 0.0, 0.0, 1.0};
         M2 Ap = A1;
