@@ -591,8 +591,9 @@ template <int VPT> struct SteadyOcc { static constexpr int waves = (VPT == 16) ?
 // at every block's first row from that block's rows, the steady-state recurrence is re-seeded at every block's first row with that block's H
 // (the oscillator itself runs on: the phase of the row is recomputed from the reference's own t, two sines per voice and block)
 template <int VPT, int C, bool GROWS, bool CROWS = false>
-__device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave)
+__device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArgs& bus, double* tile, int lane, int wave, double* osc_store = nullptr)
 {
+    constexpr bool OSC_LDS = CROWS && VPT >= 8;                                // the per-span oscillator parts in LDS instead of registers (osc_store)
     constexpr int R = kPairs / C;          // rows per flush
     constexpr int LC = SteadyVariants<VPT>::at(0);     // voice slots that can carry a homogeneous part (all of them up to 8 per lane)
     static_assert(R % 2 == 0, "the two-term recurrence rotates two registers per voice: row groups are even");
@@ -672,12 +673,18 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
             return;
         }
     }
-    [[maybe_unused]] OscPart osc[CROWS ? VPT : 1];                             // CROWS: what the per-block constants need of the oscillator (once per span)
+    [[maybe_unused]] OscPart osc[(CROWS && !OSC_LDS) ? VPT : 1];               // CROWS: what the per-block constants need of the oscillator (once per span)
+    auto osc_slot = [&](int field, int i) -> double& { return osc_store[((size_t)field * VPT + i) * SIG_WAVE + lane]; };
     if constexpr (CROWS) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = (v0 + i < a.voices) ? v0 + i : vc;
-            osc[i] = steady_osc_part(a.type, a.hertz[(int64_t)v * a.hs], a.rate, a.ctx);
+            const OscPart made = steady_osc_part(a.type, a.hertz[(int64_t)v * a.hs], a.rate, a.ctx);
+            if constexpr (OSC_LDS) {
+                osc_slot(0, i) = made.ct; osc_slot(1, i) = made.st; osc_slot(2, i) = made.beta; osc_slot(3, i) = made.enr; osc_slot(4, i) = made.eni;
+            } else {
+                osc[i] = made;
+            }
         }
     }
     double z0h[LC], z1h[LC];
@@ -813,7 +820,9 @@ __device__ __forceinline__ void steady_bus_wave(const FusedArgs& a, const BusArg
                 const double cutoff = cut_i[i], gain = gain_i[i];
                 const double hz_v = a.hertz[(int64_t)v * a.hs], ph_v = a.phase ? a.phase[(int64_t)v * a.ps] : 0.0;
                 // the oscillator's part is kept per voice for c = ctx; the launch's first block may have a shorter context
-                OscPart op = osc[i];
+                OscPart op;
+                if constexpr (OSC_LDS) op = OscPart{osc_slot(0, i), osc_slot(1, i), osc_slot(2, i), osc_slot(3, i), osc_slot(4, i)};
+                else op = osc[i];
                 if (__builtin_expect(c != a.ctx, 0)) op = steady_osc_part(a.type, hz_v, a.rate, c);      // (wave-uniform, the first block of a stream only)
                 const double ct_i = op.ct, st_i = op.st;
                 const BlockVoice cv = steady_block_constants(a.type, a.rate, cutoff, gain, op, c);
@@ -906,9 +915,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CROWS ? 1 :
 void fused_steady_bus_kernel(FusedArgs a, BusArgs bus)
 {
     __shared__ double lds[4][kPairs * kTileStride];
+    // per-block constants at 8 voices per lane: the per-span oscillator parts (5 doubles per voice) do not fit the register file
+    // beside the row state -- they live here, [wave][field][voice][lane], 80 KiB per workgroup (one workgroup per CU: the kernel
+    // runs one wave per SIMD anyway)
+    constexpr bool kOscInLds = CROWS && VPT >= 8;
+    __shared__ double osc_lds[kOscInLds ? 4 * 5 * VPT * SIG_WAVE : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform BY CONSTRUCTION: tell the compiler, so that
-    steady_bus_wave<VPT, C, GROWS, CROWS>(a, bus, lds[wave], lane, wave);      // everything derived from it lives in SGPRs and branches are scalar
+    steady_bus_wave<VPT, C, GROWS, CROWS>(a, bus, lds[wave], lane, wave,       // everything derived from it lives in SGPRs and branches are scalar
+                                          kOscInLds ? osc_lds + (size_t)wave * 5 * VPT * SIG_WAVE : nullptr);
     if (bus.out) sig_bus::sum_tiles_in_workgroup<C>(bus.partials, a.voice_tiles, bus.rows, a.span, a.K, a.N, bus.out, bus.out_ld, lane, wave);
 }
 
@@ -993,11 +1008,11 @@ int launch_rows(FusedArgs a, BusArgs bus, float* out, int64_t out_ld, hipStream_
             BusPlan plan = plan_voice_bus(a, KIND);
             if (plan.steady) {
                 if (plan.vpt > 8) plan.vpt = 8;
-                // per-block constants: 2 voices per lane (at 8 the per-span oscillator parts push the kernel past 512 registers, and
-                // the spills around every block's set-up cost 20 us of scratch round trips per block; at 4 it needs 335 and runs one
-                // wave per SIMD, whose long dependent chains -- divisions, square roots, polynomials -- nothing overlaps: 195
-                // registers at 2 leave room for a second wave, 131 -> 122 us per 1024 blocks); tuning hook: as forced
-                if (!gain_only && plan.vpt > 2 && tuning().vpt == 0) plan.vpt = 2;
+                // per-block constants: 8 voices per lane where the launch is big enough for them (one wave per SIMD; the per-span
+                // oscillator parts then live in LDS -- in registers the kernel passed 512 and spilled 132, 20 us of scratch round
+                // trips per block), else 2 (195 registers: two waves per SIMD under the constants' long dependent chains; 4 need
+                // 335 and run one wave, 7 % slower than 2).  Tuning hook: as forced
+                if (!gain_only && tuning().vpt == 0) plan.vpt = (plan.vpt >= 8) ? 8 : (plan.vpt > 2 ? 2 : plan.vpt);
                 a.span = plan.span;
                 a.steady = 1;
                 // a swept cutoff (with or without a tremolo): per-(block, voice) filter constants; a tremolo alone: the bus

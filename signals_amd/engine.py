@@ -1414,7 +1414,9 @@ class _VoiceChain:
                 key = (id(controls[0]), id(controls[1]), id(controls[2]) if not swept else None, id(pan), K, swept)
                 if held is None or held[0] != key:
                     plan = _native.fused_voice_bus_plan('Sine', b.pos, v, N, K, CONTEXT)
-                    vpl = min(plan['voices_per_lane'], 2 if swept else 8)          # (per-block constants: the kernel takes two voices per lane)
+                    vpl = min(plan['voices_per_lane'], 8)
+                    if swept and vpl < 8:
+                        vpl = min(vpl, 2)                                        # (per-block constants: eight voices per lane, or two)
                     if not plan['closed_form']:
                         index = None
                     elif not swept:
