@@ -1,9 +1,12 @@
-"""Run-time specialisation of the voice-program kernel (signals_amd/csrc/voice_program.hip).
+"""Run-time specialisation of the two interpreted kernels: voice programs (signals_amd/csrc/voice_program.hip) and block-rate
+control programs (control_program.hip).
 
 The interpreter pays for its generality: the dispatch loop carries the whole register file through a `switch`, and the
 register allocator copies ~34 doubles per instruction word back into place.  The SAME source built with the
 program as a compile-time constant (`-DSIG_VP_STATIC_CODE={...}`) unrolls that loop and folds every switch: straight-line
-HIP for exactly one voice graph, 1.5-1.7x the interpreter's rate.  This module builds such an image with the ROCm compiler
+HIP for exactly one voice graph, 1.6-2x the interpreter's rate.  Control programs likewise, keyed by their STRUCTURE (ops, register
+indices, which instructions are wide; `-DSIG_CTL_STATIC_INS / _OUTS`): their registers become VGPRs instead of an LDS file
+behind an interpretive loop, 2.3-5x.  This module builds such an image with the ROCm compiler
 (`hipcc --genco`, ~3 s; cross-compiles without a GPU), caches it next to the package keyed by the kernel sources and the
 build's parameters, and attaches it to the library (`sig_voice_program_attach`), which from then on launches it whenever
 `sig_voice_program` is called with that program.  No hipcc, or a failed build: the interpreter keeps running (it is the
