@@ -663,6 +663,22 @@ def main():
                                              'plus a launch per 67 M voice-samples; giving a block to 2 / 4 waves changes nothing (24.0 / 31.9 us '
                                              'against 24.4), so the round is issue-bound already: ~13 us of arithmetic (12.5 us inside a long '
                                              'batch) + launch and drain (tools/time_fused_geom.py, tools/time_k256.py, DESIGN.md 7)'}
+            if k in (256, 1024):
+                # the same batches over two alternating HIP streams (BatchRenderer(pipeline=2): each stream its own workspace, the
+                # caller's stream waits for every batch; the same bits): the tail of one launch under the head of the next
+                rp = BatchRenderer(build_graph(params, 0, V), 2, RATE, pipeline=2)
+                pos = N * k
+                for i in range(20):
+                    rp.render(pos, N, k); pos += N * k
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(reps):
+                    if i % wrap == 0:
+                        pos = N * k
+                    rp.render(pos, N, k); pos += N * k
+                torch.cuda.synchronize()
+                dtp = (time.perf_counter() - t0) / reps
+                entry['two_streams'] = {'Msamples_per_s': V * N * k / dtp / 1e6, 'ms_per_step': dtp * 1e3}
             by_batch[str(k)] = entry
 
     latency = None

@@ -636,12 +636,14 @@ class FusedVoiceBusCall:
         self._prepared, self._walk = lib().sig_fused_voice_bus_prepared, lib().sig_fused_voice_bus_walk
         self.shape = (rows, bus_channels)
 
-    def __call__(self, position: int, out: torch.Tensor, consts_ready: bool, walk: bool = False) -> torch.Tensor:
-        """`out`: a contiguous float32 (nblocks * block_frames, bus_channels) tensor on the launch device"""
+    def __call__(self, position: int, out: torch.Tensor, consts_ready: bool, walk: bool = False, stream: int | None = None) -> torch.Tensor:
+        """`out`: a contiguous float32 (nblocks * block_frames, bus_channels) tensor on the launch device; `stream`: a raw
+        hipStream_t to launch on instead of torch's current one (the caller orders it against whoever reads `out`)"""
+        s = _stream(out) if stream is None else stream
         if walk:
-            err = self._walk(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, _stream(out))
+            err = self._walk(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, s)
         else:
-            err = self._prepared(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, _stream(out),
+            err = self._prepared(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, s,
                                  self._consts, 1 if consts_ready else 0)
         if err:
             raise NativeError(f'sig_fused_voice_bus failed: hipError_t {err}')

@@ -184,7 +184,7 @@ class BatchRenderer:
 
     def __init__(self, node: Emitter, channels: int, rate: int = 48000, timer: KernelTimer | None = None,
                  fuse: bool = True, fuse_bus: bool = True, graph_replay: bool = False, fuse_program: bool | None = None,
-                 specialise: bool | str | None = None):
+                 specialise: bool | str | None = None, pipeline: int = 1):
         """`fuse`: let Filter(Osc) [and a Gain on top] run as one kernel when the intermediate outputs have
         no other consumer (sig_fused_osc_biquad); `fuse_bus`: also fold a SumBus on top into that launch
         (sig_fused_voice_bus).  fuse=False = one kernel per node, bit-identical to the eager path.
@@ -197,6 +197,11 @@ class BatchRenderer:
         arithmetic as straight-line code, 1.6-2x its rate; without hipcc the interpreter keeps running.  'background': the build
         runs on a worker thread and the interpreter renders until the kernel is attached (a real-time sink never waits for
         the compiler).  Default: off, or the environment's SIG_SPECIALISE=1.
+        `pipeline` (2 or 3; default 1 = off): consecutive batches of a graph that is ONE fused launch without history (the C2
+        voice graph) go to alternating HIP streams, each with its own workspace, so the tail of one launch overlaps the head of
+        the next (a 256-block batch is a single round of waves: 24.4 -> ~18 us per batch).  The caller's stream waits for each
+        batch, so the returned tensor is ordered like any other -- but it comes from a ring of 4 buffers per stream and is
+        OVERWRITTEN by the (4 x pipeline)-th render after it: consume or copy it before (like `graph_replay`).
         `timer`: optional KernelTimer that brackets every launch with HIP events.
         `graph_replay`: in the latency regime, capture the launch sequence of a one-plan graph into a hipGraph
         and replay it per call; the returned tensor is then owned by the graph and OVERWRITTEN by the next
@@ -224,6 +229,8 @@ class BatchRenderer:
         # one kernel per node (_VoiceProgram.worthwhile), 'always': wherever the graph compiles
         self.fuse_program = fuse if fuse_program is None else (fuse and fuse_program)
         self.specialise = bool(int(os.environ.get('SIG_SPECIALISE', '0'))) if specialise is None else specialise
+        self.pipeline = max(1, int(pipeline))
+        self._pipe = None                                  # streams, workspaces, pre-bound calls and output rings of the pipelined replay
         self._status: dict[Emitter, runtime.StatusWord] = {}
         self._workspace: torch.Tensor | None = None       # f64 scratch of the fused bus kernel, reused
         self._latency_ws = None                            # ((voices, N, C), zero-initialised scratch of sig_latency_voice_bus)
@@ -1528,7 +1535,59 @@ class _VoiceChain:
 
         bound = [None]                                       # (live key, LatencyVoiceBusCall) of the one-launch block
 
+        RING = 4
+
+        def pipelined(position: int):
+            """the batch at `position` on the next of `o.pipeline` streams, or None when the fast path does not apply (first
+            call, parameters re-uploaded, a position inside the first context, the walker's range): the caller falls through"""
+            key = self.live_key(self.bus_node)
+            held, pipe = o._steady_consts, o._pipe
+            if key is None or held is None or len(held) < 5 or held[0][-1] != CONTEXT or position < CONTEXT:
+                return None
+            if pipe is None or pipe['held'] is not held or len(pipe['key']) != len(key) or not all(a is b for a, b in zip(key, pipe['key'])) \
+                    or pipe['shape'] != (rows, bus_c):
+                # set-up (once per set of parameter uploads): the constants are in held[2] (made by the plain path on the caller's
+                # stream: the device is synchronised once here so that the side streams may read them and the ordered rows)
+                held_ctl, held_pan = held[1]
+                if len(key) != len(held_ctl) + 1 or key[-1] is not held_pan or \
+                        not all(k is None or k is t for k, t in zip(key, held_ctl)):
+                    return None                                                # (the constants belong to other uploads: the plain path renews them first)
+                torch.cuda.synchronize()
+                ctl_o, pan_o = held[4]
+                ws_size = _native.lib().sig_fused_voice_bus_workspace(v, rows, bus_c) // 8
+                streams = [torch.cuda.Stream() for _ in range(o.pipeline)]
+                work = [torch.empty(ws_size, dtype=CTRL_DTYPE, device=dev) for _ in streams]
+                pipe = o._pipe = {
+                    'held': held, 'key': key, 'shape': (rows, bus_c), 'i': 0, 'streams': streams, 'work': work,
+                    'handles': [s_.cuda_stream for s_ in streams],
+                    'events': [torch.cuda.Event() for _ in streams],
+                    'calls': [_native.FusedVoiceBusCall(self.kind, self.btype, rate, N, K, CONTEXT, v, ctl_o[0], ctl_o[1], ctl_o[2], ctl_o[3],
+                                                        pan_o, bus_c, w, status, held[2]) for w in work],
+                    'outs': [[torch.empty((rows, bus_c), dtype=AUDIO_DTYPE, device=dev) for _ in range(RING)] for _ in streams],
+                    'slot': [0] * len(streams)}
+                torch.cuda.synchronize()
+            per_frame, ph_max = held[3]
+            if self.kind == 'Sine' and ph_max + (position + rows) * per_frame >= _native.SINE_FAST_MAX_CYCLES:
+                return None                                                    # (beyond the closed form's range: the plain path picks the walker)
+            i = pipe['i']
+            pipe['i'] = (i + 1) % len(pipe['streams'])
+            slot = pipe['slot'][i]
+            pipe['slot'][i] = (slot + 1) % RING
+            out = pipe['outs'][i][slot]
+            call, handle = pipe['calls'][i], pipe['handles'][i]
+            if o.timer is not None:
+                o.timer.launch(bus_name, lambda: call(position, out, True, False, stream=handle), units=rows * v)
+            else:
+                call(position, out, True, False, stream=handle)
+            pipe['events'][i].record(pipe['streams'][i])                     # the caller's stream waits for this batch (raw
+            torch.cuda.current_stream().wait_event(pipe['events'][i])         # hipEventRecord / hipStreamWaitEvent through ctypes: no faster)
+            return out
+
         def replay(position: int) -> torch.Tensor:
+            if o.pipeline > 1 and not small and (o.timer is None or o.timer.region):
+                done = pipelined(position)
+                if done is not None:
+                    return done
             if one_launch and o.timer is None:
                 # latency mode, the per-block host path: five identity checks, one allocation, one ctypes call (a hipGraph of
                 # this single launch would only add its replay cost: 19.6 us per block against 14.6)

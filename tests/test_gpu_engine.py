@@ -1089,3 +1089,45 @@ def test_two_oscillators_through_mix_or_ringmod_in_front_of_the_filter(golden):
                 ref = np.concatenate([R.render(node, 300 + i * N, N, V, RATE) for i in range(K + 2)])
                 ref = R.sum_bus(ref) if bus else ref
                 assert maxerr(got, f32(ref)) < 1e-6, (op, kind_a, kind_b, bus)
+
+
+@pytest.mark.parametrize('pipeline', [2, 3])
+def test_pipelined_batches_over_alternating_streams_equal_the_plain_render(pipeline):
+    """BatchRenderer(pipeline=n): consecutive batches of a one-launch graph (C2: osc.py:26-62 -> fx.py:85-121 -> fx.py:49-52 ->
+    bus) on alternating HIP streams, each with its own workspace, the caller's stream waiting for each -- the same bits as the
+    plain render, for a stream of batches consumed with a lag, across a parameter edit (the constants are renewed, the streams
+    re-bound) and for a first batch inside the first context (which the plain path takes)"""
+    from signals_amd.chain import ext, fx
+    from signals_amd.engine import BatchRenderer, KernelTimer
+    V, N, K = 256, 256, 8
+    rng = np.random.default_rng(31)
+    hz, ph = rng.uniform(55, 1760, (1, V)), rng.uniform(0, 1, (1, V))
+    cut, gain = rng.uniform(200, 8000, (1, V)), rng.uniform(0.1, 1, (1, V)) / V
+    th = rng.uniform(0, np.pi / 2, V)
+    pan = np.ascontiguousarray(np.stack([np.cos(th), np.sin(th)]))
+
+    def build():
+        f = fx.LowPass(); f.input = mkosc('Sine', hz, ph); f.cutoff = fix(cut)
+        g = fx.Gain(); g.left = f; g.right = fix(gain)
+        b = ext.SumBus(); b.input = g; b.get_state().gains = pan
+        return b, g
+    plain = BatchRenderer(build()[0], 2, RATE)
+    bus, gain_node = build()
+    timer = KernelTimer(region=True)
+    piped = BatchRenderer(bus, 2, RATE, pipeline=pipeline, timer=timer)
+    plain.scan_max_chains = piped.scan_max_chains = 0        # (not the latency regime's scan kernels: the batch launch)
+    pos, held = 0, []
+    for i in range(14):
+        if i == 9:                                               # an in-place edit of a parameter array: seen at the next render (fixed.py:38-39)
+            gain_node.right.sig.get_state().value[0, :7] *= 0.5
+            plain.node.input.sig.right.sig.get_state().value[0, :7] *= 0.5
+        got = piped.render(pos, N, K)
+        want = plain.render(pos, N, K)
+        held.append((got.clone(), want.clone()))                 # (the pipelined reply is borrowed: copied before it is overwritten)
+        pos += N * K
+    timer.close()
+    torch.cuda.synchronize()
+    for i, (got, want) in enumerate(held):
+        assert torch.equal(got, want), i
+    assert piped._pipe is not None and len(piped._pipe['streams']) == pipeline
+    assert set(timer.summary()) == {'fused_voice_bus[Sine,lp,gain]'}
