@@ -371,6 +371,19 @@ int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t rate, int6
                                  double* workspace, float* out, int64_t out_ld, int32_t* status, void* stream,
                                  double* consts, int32_t consts_ready);
 
+/* sig_fused_voice_bus_prepared (walk == 0) / sig_fused_voice_bus_walk (walk != 0) with every argument that does not change from
+ * batch to batch in a caller-held block: what a host binding with a per-argument cost (ctypes: ~5 us for 26 arguments, a
+ * quarter of a 256-block batch) calls per batch.  `consts` may be NULL when only the walker is ever asked for. */
+typedef struct {
+    int32_t osc_kind, filt_type, rate, block_frames, nblocks, context, voices;
+    int32_t hertz_stride, phase_stride, cutoff_stride, gain_stride, bus_channels;
+    const double* hertz; const double* phase; const double* cutoff; const double* gain; const double* bus_gains;
+    int64_t bus_gains_ld, out_ld;
+    double* workspace; int32_t* status; double* consts;
+} sig_fused_voice_bus_call;
+int sig_fused_voice_bus_bound(const sig_fused_voice_bus_call* call, int64_t position, float* out, int32_t consts_ready,
+                              int32_t walk, void* stream);
+
 /* Fused filter cascade + envelope + sum bus (BASELINE config 3's whole graph in one launch):
  *   out[n,c] = sum_v bus_gains[c,v] * [gain[v] *] [ADSR_v(n) *] Filter2(Filter1(Osc))[n,v]
  * i.e. Osc._eval (chain/osc.py:26-62), two CritFilter._filter (chain/fx.py:85-121) in series with the reference's

@@ -35,7 +35,7 @@ EXPORTS = ('sig_abi_version', 'sig_osc_bank', 'sig_osc_bank_mod', 'sig_biquad_co
            'sig_fused_osc_biquad_fm', 'sig_fused_voice_bus_fm', 'sig_control_program',
            'sig_voice_program', 'sig_voice_program_set_tuning', 'sig_voice_program_geometry', 'sig_voice_program_args_size',
            'sig_voice_program_attach', 'sig_voice_program_detach_all', 'sig_voice_program_use_attached',
-           'sig_control_program_attach', 'sig_control_program_attached')
+           'sig_control_program_attach', 'sig_control_program_attached', 'sig_fused_voice_bus_bound')
 
 
 class NativeError(RuntimeError):
@@ -189,6 +189,8 @@ def lib() -> ctypes.CDLL:
         L.sig_control_program_attach.argtypes = [ctypes.POINTER(i32), i32, ctypes.c_char_p, ctypes.POINTER(i32)]
         L.sig_control_program_attached.restype = ctypes.c_int
         L.sig_control_program_attached.argtypes = [i32, i32, i64, i32, i32, i32, i64, i64, vp, i32, vp, i32, vp]
+        L.sig_fused_voice_bus_bound.restype = ctypes.c_int
+        L.sig_fused_voice_bus_bound.argtypes = [vp, i64, vp, i32, i32, vp]
         L.sig_voice_program.restype = ctypes.c_int
         L.sig_voice_program.argtypes = [ctypes.POINTER(VoiceProgramT), i32, i64, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int64), i32,
                                         dp, i64, i32, vp, vp, i64, vp, vp]
@@ -251,6 +253,13 @@ def _stream(t: torch.Tensor) -> int:
     if _raw_stream is not None:
         return _raw_stream(t.device.index)              # the same handle as below, without building a Stream object
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def current_stream_handle(device_index: int) -> int:
+    """the raw hipStream_t torch currently launches on"""
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def _ctrl_row(t: torch.Tensor | None, what: str):
@@ -600,6 +609,15 @@ class LatencyVoiceBusCall:
         return out
 
 
+class FusedVoiceBusCallT(ctypes.Structure):
+    """sig_fused_voice_bus_call (host memory)"""
+    _fields_ = [(n, ctypes.c_int32) for n in ('osc_kind', 'filt_type', 'rate', 'block_frames', 'nblocks', 'context', 'voices',
+                                              'hertz_stride', 'phase_stride', 'cutoff_stride', 'gain_stride', 'bus_channels')] + \
+               [(n, ctypes.c_void_p) for n in ('hertz', 'phase', 'cutoff', 'gain', 'bus_gains')] + \
+               [('bus_gains_ld', ctypes.c_int64), ('out_ld', ctypes.c_int64), ('workspace', ctypes.c_void_p), ('status', ctypes.c_void_p),
+                ('consts', ctypes.c_void_p)]
+
+
 class FusedVoiceBusCall:
     """`fused_voice_bus` with caller-held closed-form constants (sig_fused_voice_bus_prepared / _walk) and everything but the
     position and the output buffer validated and converted ONCE: the per-batch host path of the batched engine is then one
@@ -635,16 +653,19 @@ class FusedVoiceBusCall:
         self._consts = consts.data_ptr()
         self._prepared, self._walk = lib().sig_fused_voice_bus_prepared, lib().sig_fused_voice_bus_walk
         self.shape = (rows, bus_channels)
+        # ... and as one block for sig_fused_voice_bus_bound: six arguments per call instead of 26
+        (hp, hs), (pp, ps), (cp, cs), (gp_, gs) = [ptrs[2 * k: 2 * k + 2] for k in range(4)]
+        self._block = FusedVoiceBusCallT(OSC_KINDS[kind], FILT_TYPES[btype], rate, block_frames, nblocks, context, voices, hs, ps, cs, gs,
+                                         bus_channels, hp, pp, cp, gp_, gp, gld, bus_channels, workspace.data_ptr(), self._status,
+                                         self._consts)
+        self._block_ref = ctypes.byref(self._block)
+        self._bound = lib().sig_fused_voice_bus_bound
 
     def __call__(self, position: int, out: torch.Tensor, consts_ready: bool, walk: bool = False, stream: int | None = None) -> torch.Tensor:
         """`out`: a contiguous float32 (nblocks * block_frames, bus_channels) tensor on the launch device; `stream`: a raw
         hipStream_t to launch on instead of torch's current one (the caller orders it against whoever reads `out`)"""
         s = _stream(out) if stream is None else stream
-        if walk:
-            err = self._walk(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, s)
-        else:
-            err = self._prepared(*self._head, position, *self._mid, out.data_ptr(), self.shape[1], self._status, s,
-                                 self._consts, 1 if consts_ready else 0)
+        err = self._bound(self._block_ref, position, out.data_ptr(), 1 if consts_ready else 0, 1 if walk else 0, s)
         if err:
             raise NativeError(f'sig_fused_voice_bus failed: hipError_t {err}')
         return out

@@ -1702,4 +1702,16 @@ extern "C" int sig_fused_voice_bus_prepared(int osc_kind, int filt_type, int32_t
                                 phase, phase_stride, cutoff, cutoff_stride, gain, gain_stride, bus_gains, bus_gains_ld,
                                 bus_channels, workspace, out, out_ld, status, stream, consts, consts_ready);
 }
+
+// sig_fused_voice_bus_prepared / _walk with everything but the position, the output and the stream in a caller-held block: a
+// host binding that marshals every argument per call (ctypes: ~5 us for the 26 of them) pays that once
+extern "C" int sig_fused_voice_bus_bound(const sig_fused_voice_bus_call* c, int64_t position, float* out, int32_t consts_ready,
+                                         int32_t walk, void* stream)
+{
+    SIG_CHECK_ARG(c != nullptr && (walk || c->consts != nullptr));
+    return fused_voice_bus_impl(c->osc_kind, c->filt_type, c->rate, position, c->block_frames, c->nblocks, c->context, c->voices,
+                                c->hertz, c->hertz_stride, c->phase, c->phase_stride, c->cutoff, c->cutoff_stride, c->gain, c->gain_stride,
+                                c->bus_gains, c->bus_gains_ld, c->bus_channels, c->workspace, out, c->out_ld, c->status, stream,
+                                walk ? nullptr : c->consts, walk ? 0 : consts_ready, walk ? 1 : 0);
+}
 #endif  // SIG_FUSED_PART_B

@@ -1579,8 +1579,12 @@ class _VoiceChain:
                 o.timer.launch(bus_name, lambda: call(position, out, True, False, stream=handle), units=rows * v)
             else:
                 call(position, out, True, False, stream=handle)
-            pipe['events'][i].record(pipe['streams'][i])                     # the caller's stream waits for this batch (raw
-            torch.cuda.current_stream().wait_event(pipe['events'][i])         # hipEventRecord / hipStreamWaitEvent through ctypes: no faster)
+            pipe['events'][i].record(pipe['streams'][i])                     # the caller's stream waits for this batch
+            raw = _native.current_stream_handle(dev.index)                     # (torch.cuda.current_stream() costs 8 us of Python: the Stream
+            cur = pipe.get('current')                                          # object is kept while the raw handle is the same)
+            if cur is None or cur[0] != raw:
+                cur = pipe['current'] = (raw, torch.cuda.current_stream())
+            cur[1].wait_event(pipe['events'][i])
             return out
 
         def replay(position: int) -> torch.Tensor:
